@@ -1,0 +1,75 @@
+"""Deterministic synthetic inputs (numpy PCG64 only, no torch) shared by tests, bench.py and
+the golden-vector generator.  Definitions follow SURVEY.md 8(d) "Synthetic inputs".
+
+There is no dataset or checkpoint in the reference tree (its .gitignore excludes them), so every
+measurement and parity test runs on these.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DCGAN_CHANNELS = [(100, 1024), (1024, 512), (512, 256), (256, 128)]  # gen.0..gen.3, features_g=64
+
+
+def lowpass_u8_images(seed, n, res=64, ch=3, cell=8):
+    """u8 images [n, ch, res, res] with spatial structure: a coarse random field, bilinearly
+    enlarged, plus fine noise.  Spans the full 0..255 range."""
+    rng = np.random.default_rng(seed)
+    g = res // cell + 1
+    coarse = rng.uniform(0.0, 255.0, size=(n, ch, g, g))
+    t = (np.arange(res) / cell)
+    i0 = np.floor(t).astype(int)
+    f = t - i0
+    rows = coarse[:, :, i0, :] * (1 - f)[None, None, :, None] + coarse[:, :, i0 + 1, :] * f[None, None, :, None]
+    img = rows[:, :, :, i0] * (1 - f)[None, None, None, :] + rows[:, :, :, i0 + 1] * f[None, None, None, :]
+    img = img + rng.normal(0.0, 6.0, size=img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def perturb_u8(seed, imgs_u8, sigma=10.0):
+    """noisy copies (re-quantised): members that sit close to, not on, a bank sample."""
+    rng = np.random.default_rng(seed)
+    x = imgs_u8.astype(np.float64) + rng.normal(0.0, sigma, size=imgs_u8.shape)
+    return np.clip(np.rint(x), 0, 255).astype(np.uint8)
+
+
+def attack_case(seed, n_bank, n_pos, n_neg, res=64, sigma=10.0):
+    """bank + positive queries (perturbed copies of randomly chosen bank images) + negative queries
+    (fresh images).  Returns dict of u8 arrays [.,3,res,res] and `pos_src` (bank index each positive
+    was derived from; with the default sigma it is also its nearest neighbour)."""
+    bank = lowpass_u8_images(seed * 1000 + 1, n_bank, res)
+    rng = np.random.default_rng(seed * 1000 + 2)
+    src = rng.integers(0, n_bank, size=n_pos)
+    pos = perturb_u8(seed * 1000 + 3, bank[src], sigma)
+    neg = lowpass_u8_images(seed * 1000 + 4, n_neg, res)
+    return {"bank": bank, "pos": pos, "neg": neg, "pos_src": src}
+
+
+def dcgan_state_dict(seed=1234, z_dim=100, channels_img=3, features_g=64, prefix="gen.", gain=1.0):
+    """Random DCGAN/WGAN-GP generator weights under the reference's key names
+    (gan_models/dcgan/model_torch.py:75-96): gen.{0..3}.0.weight [Ci,Co,4,4],
+    gen.{0..3}.1.{weight,bias,running_mean,running_var,num_batches_tracked}, gen.4.{weight,bias}.
+    Conv weights are scaled so activations stay O(1) through the stack and the tanh output uses
+    most of (-1,1); BN statistics are randomised so that folding them is exercised."""
+    rng = np.random.default_rng(seed)
+    fg = features_g
+    chans = [(z_dim, fg * 16), (fg * 16, fg * 8), (fg * 8, fg * 4), (fg * 4, fg * 2)]
+    sd = {}
+    for i, (ci, co) in enumerate(chans):
+        taps = 16 if i == 0 else 4          # contributing taps per output pixel
+        std = gain * np.sqrt(2.0 / (ci * taps))
+        sd[f"{prefix}{i}.0.weight"] = rng.normal(0.0, std, size=(ci, co, 4, 4)).astype(np.float32)
+        sd[f"{prefix}{i}.1.weight"] = rng.normal(1.0, 0.1, size=co).astype(np.float32)
+        sd[f"{prefix}{i}.1.bias"] = rng.normal(0.0, 0.1, size=co).astype(np.float32)
+        sd[f"{prefix}{i}.1.running_mean"] = rng.normal(0.0, 0.1, size=co).astype(np.float32)
+        sd[f"{prefix}{i}.1.running_var"] = rng.uniform(0.5, 1.5, size=co).astype(np.float32)
+        sd[f"{prefix}{i}.1.num_batches_tracked"] = np.array(1, np.int64)
+    ci = fg * 2
+    sd[f"{prefix}4.weight"] = rng.normal(0.0, 1.5 * np.sqrt(1.0 / (ci * 4)), size=(ci, channels_img, 4, 4)).astype(np.float32)
+    sd[f"{prefix}4.bias"] = rng.normal(0.0, 0.1, size=channels_img).astype(np.float32)
+    return sd
+
+
+def latent(seed, n, z_dim=100):
+    """z ~ N(0,1), float32 [n, z_dim, 1, 1] (dcgan/train_torch.py:153)."""
+    return np.random.default_rng(seed).standard_normal((n, z_dim)).astype(np.float32).reshape(n, z_dim, 1, 1)

@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own code on seeded synthetic inputs.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+The reference modules are imported in place (tests/golden/_refimport.py); only the resulting
+vectors (inputs are re-derivable from seeds; outputs are stored) are committed.
+
+What is exercised, per file written:
+  knn_*.npz    attack_models/fbb.py:73-88 custom_knn, driven with the L2 lambda of
+               attack_models/utils.py:163 (Loss(...) itself cannot be constructed offline: its
+               __init__ always builds LPIPS and fetches VGG16 weights, utils.py:157)
+  roc_*.npz    attack_models/eval_roc.py:14-25 plot_roc
+  dcgan_gen.npz  gan_models/dcgan/model_torch.py:75-96 Generator (eval) and
+                 gan_models/wgangp/model.py:37-58 Generator on the same weights
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+import _refimport  # noqa: E402
+
+
+def _load_local(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_local("gl_synth", os.path.join(ROOT, "gan-leaks_amd", "synth.py"))
+oracle = _load_local("gl_oracle", os.path.join(ROOT, "oracle", "oracle.py"))
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+# the reference's L2 branch, attack_models/utils.py:163 + :171-177 with loss_lpips == 0.
+def ref_l2_loss(x_hat, x_gt):
+    return 0.2 * 0.0 + torch.mean((x_gt - x_hat) ** 2, dim=[1, 2, 3])
+
+
+def to_ref_tensor(u8):
+    """what fbb.main builds from PNG files: utils.read_image (float64 2*(u/255)-1, HWC) ->
+    np.array -> torch .float() -> permute NCHW  (fbb.py:133-135).  Our u8 arrays are CHW already."""
+    f64 = 2.0 * (u8.astype(np.float64) / 255.0) - 1.0
+    return torch.from_numpy(f64).float()
+
+
+KNN_CASES = {
+    # name: (seed, n_bank, n_pos, n_neg, res, batch_size)
+    "knn_c1": (11, 1000, 128, 128, 64, 64),      # BASELINE.json configs[0]
+    "knn_b30": (12, 1000, 16, 16, 64, 30),       # argparse default BATCH_SIZE (fbb.py:33)
+    "knn_res32": (13, 300, 24, 24, 32, 64),
+    "knn_res16": (14, 131, 8, 8, 16, 64),        # ragged: 131 -> 128 used
+}
+
+
+def make_knn(fbb):
+    for name, (seed, nb, npos, nneg, res, bs) in KNN_CASES.items():
+        case = synth.attack_case(seed, nb, npos, nneg, res)
+        bank = to_ref_tensor(case["bank"])
+        args = types.SimpleNamespace(BATCH_SIZE=bs)
+        out = {}
+        for kind in ("pos", "neg"):
+            q = to_ref_tensor(case[kind])
+            d, i = [], []
+            for sample in q:
+                dd, ii = fbb.custom_knn(bank, sample, ref_l2_loss, args)
+                d.append(dd)
+                i.append(ii)
+            out[kind + "_dist"] = np.array(d, np.float64)
+            out[kind + "_idx"] = np.array(i, np.int64)
+        np.savez(os.path.join(HERE, name + ".npz"), seed=seed, n_bank=nb, n_pos=npos, n_neg=nneg,
+                 res=res, batch_size=bs, **out)
+        print(name, "pos idx == src:", np.mean(out["pos_idx"] == case["pos_src"]))
+
+    # ties / truncation / exact-hit case, bank built by hand from a synthetic base
+    base = synth.lowpass_u8_images(77, 1000, 64)
+    bank = base.copy()
+    bank[700] = bank[5]
+    bank[300] = bank[5]          # three identical samples: first index (5) must win
+    queries = np.stack([
+        bank[5],                 # exact hit, S = 0, ties at 5/300/700
+        bank[990],               # its twin lives in the truncated tail (>= 960): must NOT be found
+        synth.perturb_u8(1, bank[700:701], 3.0)[0],
+        bank[959],               # last usable index
+        bank[0],
+    ])
+    args = types.SimpleNamespace(BATCH_SIZE=64)
+    bt = to_ref_tensor(bank)
+    d, i = [], []
+    for sample in to_ref_tensor(queries):
+        dd, ii = fbb.custom_knn(bt, sample, ref_l2_loss, args)
+        d.append(dd)
+        i.append(ii)
+    np.savez(os.path.join(HERE, "knn_ties.npz"), dist=np.array(d, np.float64), idx=np.array(i, np.int64),
+             batch_size=64)
+    print("knn_ties idx", i)
+
+    # bank smaller than one batch: record the reference's exception type
+    try:
+        fbb.custom_knn(bt[:10], to_ref_tensor(queries)[0], ref_l2_loss, args)
+        err = "none"
+    except Exception as e:  # noqa: BLE001
+        err = type(e).__name__
+    with open(os.path.join(HERE, "knn_empty_error.txt"), "w") as f:
+        f.write(err + "\n")
+    print("empty-bank error:", err)
+
+
+def make_roc(ev):
+    rng = np.random.default_rng(5)
+    cases = {
+        "roc_sep": (rng.gamma(2.0, 0.05, 300), rng.gamma(4.0, 0.05, 300)),
+        "roc_ties": (np.round(rng.gamma(2.0, 0.05, 200), 2), np.round(rng.gamma(3.0, 0.05, 150), 2)),
+        "roc_small": (np.array([0.1, 0.2, 0.05]), np.array([0.3, 0.1])),
+    }
+    # plus one built from a real knn case
+    k = np.load(os.path.join(HERE, "knn_c1.npz"))
+    cases["roc_knn_c1"] = (k["pos_dist"], k["neg_dist"])
+    for name, (pos, neg) in cases.items():
+        pos = np.asarray(pos, np.float64).reshape(-1, 1)   # fbb.py:160 saves [Q,1] float64
+        neg = np.asarray(neg, np.float64).reshape(-1, 1)
+        fpr, tpr, thr, auc, ap, prec = ev.plot_roc(-pos, -neg)   # eval_roc.py:78
+        np.savez(os.path.join(HERE, name + ".npz"), pos_loss=pos, neg_loss=neg, fpr=fpr, tpr=tpr,
+                 thr=thr, auc=auc, ap=ap, precision=prec)
+        print(name, "auc %.6f ap %.6f prec %.6f" % (auc, ap, prec))
+
+
+def make_dcgan(dc, wg):
+    sd_np = synth.dcgan_state_dict(1234)
+    z = synth.latent(1, 8)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    outs = {}
+    for tag, mod in (("dcgan", dc), ("wgangp", wg)):
+        g = mod.Generator(100, 3, 64)
+        missing = g.load_state_dict(sd, strict=True)
+        g.eval()                                           # dcgan/train_torch.py:150
+        with torch.no_grad():
+            outs[tag] = g(torch.from_numpy(z)).numpy()
+        print(tag, "load:", missing, "out range", outs[tag].min(), outs[tag].max(), "std", outs[tag].std())
+    assert np.array_equal(outs["dcgan"], outs["wgangp"]) or np.allclose(outs["dcgan"], outs["wgangp"], atol=1e-6)
+    # privGAN stack: generator 0 of stackGenerators (privDCGAN.py:192)
+    st = dc.stackGenerators(100, 3, 64, 2)
+    sd_stack = {}
+    for gi in range(2):
+        s = synth.dcgan_state_dict(1234 + gi, prefix=f"gen.{gi}.gen.")
+        sd_stack.update({k: torch.from_numpy(np.asarray(v)) for k, v in s.items()})
+    st.load_state_dict(sd_stack, strict=True)
+    st.eval()
+    with torch.no_grad():
+        o1 = st(torch.from_numpy(z), 1).numpy()
+    np.savez(os.path.join(HERE, "dcgan_gen.npz"), weight_seed=1234, z_seed=1, n=8, out=outs["dcgan"],
+             out_wgangp=outs["wgangp"], stack_out_g1=o1)
+    # also check the numpy oracle right here
+    o = oracle.dcgan_generator_forward(sd_np, z)
+    print("oracle vs reference generator: max abs diff", np.abs(o - outs["dcgan"]).max())
+
+
+if __name__ == "__main__":
+    fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
+    make_knn(fbb)
+    ev = _refimport.load("attack_models/eval_roc.py", "ref_eval_roc")
+    make_roc(ev)
+    dc = _refimport.load("gan_models/dcgan/model_torch.py", "ref_dcgan_model")
+    wg = _refimport.load("gan_models/wgangp/model.py", "ref_wgangp_model")
+    make_dcgan(dc, wg)
