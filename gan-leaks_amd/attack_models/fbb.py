@@ -1,0 +1,170 @@
+"""Counterpart of the reference's attack_models/fbb.py (the full-black-box attack driver).
+
+Same command line, YAML overlay, output files and `custom_knn` signature; underneath, the whole
+query set is searched in one launch of the HIP pairwise kernel instead of Q x (N / BATCH_SIZE)
+Python iterations (attack_models/fbb.py:156-159, 73-88).
+
+Additions (flagged [build] in SURVEY.md 5): --distance {l2,l2-lpips} (the reference hard-wires
+'l2-lpips', fbb.py:148).  The reference has no `attack()`; the batched entry point named by the
+project brief lives in ganleaks_amd.attack.attack and is re-exported here.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+import warnings
+
+import numpy as np
+
+from ..attack import Bank, attack  # noqa: F401  (re-export)
+from .utils import (Loss, check_folder, get_filepaths_from_dir, read_images_u8_nchw, save_files)
+
+
+def parse_arguments(argv=None):
+    """attack_models/fbb.py:18-38: identical flags and defaults, plus --distance."""
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--exp_name', '-name', type=str, default='debug',
+                        help='the name of the current experiment (used to set up the save_dir)')
+    parser.add_argument('--syn_data_path', type=str, help='directory to the synthetic data')
+    parser.add_argument('--pos_data_dir', type=str, default=os.path.join(os.getcwd(), 'data', 'miniCelebA', 'train'),
+                        help='the directory for the positive (training) query images set')
+    parser.add_argument('--neg_data_dir', type=str, default=os.path.join(os.getcwd(), 'data', 'miniCelebA', 'test'),
+                        help='the directory for the negative (testing) query images set')
+    parser.add_argument('--data_num', '-dnum', type=int, default=20000, help='the number of query images to be considered')
+    parser.add_argument('--resolution', '-resolution', type=int, default=64, help='generated image resolution')
+    parser.add_argument('--K', type=int, default=5)
+    parser.add_argument('--BATCH_SIZE', type=int, default=30)
+    parser.add_argument('--local_config', type=str, default=None)
+    parser.add_argument('--hyperparameter_search', default=False, help='tune hyperparameters')
+    parser.add_argument('--params', type=str, default=None, help='hyperparameters to tune')
+    parser.add_argument("--wandb", default=None, help="accepted for compatibility; logging to WandB is not performed")
+    parser.add_argument('--distance', type=str, default='l2-lpips', choices=['l2', 'l2-lpips'],
+                        help="[build] distance operator; the reference always uses 'l2-lpips' (fbb.py:148)")
+    return parser.parse_args(argv)
+
+
+def check_args(args):
+    """attack_models/fbb.py:42-67: save_dir = ./fbb_attack/<exp_name>[/<params>], params.txt + params.pkl"""
+    assert os.path.exists(args.syn_data_path)
+    if args.params is not None and args.hyperparameter_search:
+        subdir = args.syn_data_path
+        exp_name = args.exp_name + '__' + subdir.split('/')[-2]
+        save_dir = os.path.join(os.getcwd(), 'fbb_attack', exp_name, args.params)
+    else:
+        save_dir = os.path.join(os.getcwd(), 'fbb_attack', args.exp_name)
+    check_folder(save_dir)
+    with open(os.path.join(save_dir, 'params.txt'), 'w') as f:
+        for k, v in vars(args).items():
+            f.writelines(k + ":" + str(v) + "\n")
+            print(k + ":" + str(v))
+    pickle.dump(vars(args), open(os.path.join(save_dir, 'params.pkl'), 'wb'), protocol=2)
+    return args, save_dir
+
+
+_bank_cache = {"key": None, "bank": None}
+
+
+def _cached_bank(syn_imgs, n_rows):
+    """custom_knn is called once per query with the same bank (fbb.py:156-159): prepare it once."""
+    if isinstance(syn_imgs, Bank):
+        return syn_imgs
+    ptr = syn_imgs.data_ptr() if hasattr(syn_imgs, "data_ptr") else (
+        syn_imgs.ctypes.data if isinstance(syn_imgs, np.ndarray) else id(syn_imgs))
+    key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows)
+    if _bank_cache["key"] != key:
+        _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows])
+        _bank_cache["key"] = key
+    return _bank_cache["bank"]
+
+
+def custom_knn(syn_imgs, sample, loss, args):
+    """attack_models/fbb.py:73-88.  syn_imgs [N,C,H,W], sample [C,H,W], loss = Loss(...) instance,
+    args.BATCH_SIZE.  Returns (min distance as python float, index as python int); only the first
+    (N // BATCH_SIZE) * BATCH_SIZE bank samples take part, first index wins ties."""
+    distance = getattr(loss, "distance", None)
+    if distance is None:
+        raise TypeError("loss must be a ganleaks_amd Loss instance (its .distance selects the kernel)")
+    n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
+    if n_rows == 0:
+        raise ValueError("torch.cat(): expected a non-empty list of Tensors")   # what fbb.py:83 raises
+    bank = _cached_bank(syn_imgs, n_rows)
+    q = sample.unsqueeze(0) if hasattr(sample, "unsqueeze") else np.asarray(sample)[None]
+    dist, idx = attack(q, bank, distance=distance, batch_size=args.BATCH_SIZE)
+    return float(dist[0]), int(idx[0])
+
+
+def plot_closest_images(idx, query_imgs_u8, syn_imgs_u8, save_dir, class_type, num=20):
+    """attack_models/fbb.py:91-106: query | nearest sample, side by side, <i><class_type>.png.
+    Works on the 8-bit codes directly (the reference converts float -> uint8 with truncation)."""
+    import PIL.Image
+    for i in range(min(num, len(idx))):
+        syn_img = syn_imgs_u8[int(idx[i][0])].transpose(1, 2, 0)
+        query_img = query_imgs_u8[i].transpose(1, 2, 0)
+        img = np.concatenate((query_img, syn_img), axis=1)
+        f = (2.0 * (img / 255.0) - 1.0 + 1.0) / 2.0
+        PIL.Image.fromarray(np.uint8(f * 255)).save(os.path.join(save_dir, str(i) + class_type + '.png'))
+
+
+def main(args):
+    """attack_models/fbb.py:111-179."""
+    if args.hyperparameter_search:
+        subdirs = [os.path.join(args.syn_data_path, o) for o in os.listdir(args.syn_data_path)
+                   if os.path.isdir(os.path.join(args.syn_data_path, o))]
+    else:
+        subdirs = [args.syn_data_path]
+    distance = getattr(args, "distance", "l2-lpips")
+    results = []
+    for subdir in subdirs:
+        args.syn_data_path = subdir
+        args.params = subdir.split('/')[-1] if args.hyperparameter_search else args.params
+        args, save_dir = check_args(args)
+        print(args)
+        print('exp_name: ', args.exp_name)
+        print('params: ', args.params)
+        resolution = args.resolution
+
+        syn_imgs = read_images_u8_nchw(get_filepaths_from_dir(subdir, ext='png'), resolution)
+        pos_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.pos_data_dir, ext='png'), resolution)
+        neg_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.neg_data_dir, ext='png'), resolution)
+
+        Loss(distance, if_norm_reg=False)           # announces / validates the distance like fbb.py:148
+        n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
+        if n_rows == 0:
+            raise ValueError("torch.cat(): expected a non-empty list of Tensors")
+        bank = Bank.from_images(syn_imgs[:n_rows])
+
+        pos_d, pos_i = attack(pos_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE)
+        pos_loss = pos_d.astype(np.float64).reshape(-1, 1)          # python floats -> float64 [Q,1] (fbb.py:160)
+        plt_pos_idx = pos_i.reshape(-1, 1)
+        save_files(save_dir, ['pos_loss', 'pos_idx'], [pos_loss, np.arange(len(pos_loss)).reshape(-1, 1)])
+
+        neg_d, neg_i = attack(neg_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE)
+        neg_loss = neg_d.astype(np.float64).reshape(-1, 1)
+        plt_neg_idx = neg_i.reshape(-1, 1)
+        # the reference writes arange(len(pos_loss)) here as well (fbb.py:171): kept
+        save_files(save_dir, ['neg_loss', 'neg_idx'], [neg_loss, np.arange(len(pos_loss)).reshape(-1, 1)])
+        # [build] the real nearest-neighbour indices, which the reference keeps only in memory
+        save_files(save_dir, ['pos_nn_idx', 'neg_nn_idx'], [plt_pos_idx, plt_neg_idx])
+
+        plot_closest_images(plt_pos_idx, pos_query_imgs, syn_imgs, save_dir, 'pos')
+        plot_closest_images(plt_neg_idx, neg_query_imgs, syn_imgs, save_dir, 'neg')
+        results.append((save_dir, pos_loss, neg_loss, plt_pos_idx, plt_neg_idx))
+    return results
+
+
+def update_args(args, config_dict):
+    """attack_models/fbb.py:182-184"""
+    for key, val in config_dict.items():
+        setattr(args, key, val)
+
+
+if __name__ == '__main__':
+    import yaml
+    args = parse_arguments()
+    if args.local_config is not None:
+        with open(str(args.local_config), "r") as f:
+            update_args(args, yaml.safe_load(f))
+    else:
+        warnings.warn("No config file was provided. Using default parameters.")
+    main(args)

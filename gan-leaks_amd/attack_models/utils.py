@@ -1,0 +1,112 @@
+"""Counterpart of the reference's attack_models/utils.py for the fbb path: file helpers and the
+distance operator `Loss`.  The plotting helpers of the reference (utils.py:90-148) are not on the
+attack path and are not provided.
+"""
+from __future__ import annotations
+
+import ctypes
+import fnmatch
+import os
+
+import numpy as np
+
+from .. import _lib
+from .._lib import Context, check
+from ..attack import prepare_images
+
+_p = ctypes.c_void_p
+
+
+def check_folder(dir):
+    """attack_models/utils.py:19-27"""
+    if not os.path.exists(dir):
+        os.makedirs(dir)
+    return dir
+
+
+def save_files(save_dir, file_name_list, array_list):
+    """attack_models/utils.py:30-40"""
+    assert len(file_name_list) == len(array_list)
+    for i in range(len(file_name_list)):
+        np.save(os.path.join(save_dir, file_name_list[i]), array_list[i], allow_pickle=False)
+
+
+def get_filepaths_from_dir(data_dir, ext):
+    """attack_models/utils.py:43-57: recursive, sorted on the path STRING (image_10 < image_2)."""
+    pattern = "*." + ext
+    path_list = []
+    for d, s, fList in os.walk(data_dir):
+        for filename in fList:
+            if fnmatch.fnmatch(filename, pattern):
+                path_list.append(os.path.join(d, filename))
+    return sorted(path_list)
+
+
+def read_image_u8(filepath, resolution=64):
+    """the 8-bit codes read_image decodes (attack_models/utils.py:71-80): PIL open, and a PIL resize
+    (default filter) to resolution x resolution when the shape differs.  HWC uint8."""
+    import PIL.Image
+    img = np.asarray(PIL.Image.open(filepath))
+    if img.shape != (resolution, resolution, 3):
+        img = np.asarray(PIL.Image.fromarray(img).resize((resolution, resolution)))
+    return img
+
+
+def read_image(filepath, resolution=64, cx=89, cy=121):
+    """attack_models/utils.py:60-84: image in [-1,1], shape (resolution, resolution, 3), float64."""
+    return 2.0 * (read_image_u8(filepath, resolution) / 255.0) - 1.0
+
+
+def read_images_u8_nchw(paths, resolution=64):
+    """all files -> uint8 [N,3,res,res] (the NCHW order fbb.main permutes to, fbb.py:135)."""
+    out = np.empty((len(paths), 3, resolution, resolution), np.uint8)
+    for i, f in enumerate(paths):
+        out[i] = read_image_u8(f, resolution).transpose(2, 0, 1)
+    return out
+
+
+class Loss:
+    """attack_models/utils.py:153-177.  Loss(distance, if_norm_reg=False); forward(x_hat, x_gt) -> [B].
+
+    x_hat [B,C,H,W], x_gt [1,C,H,W] (broadcast) or [B,C,H,W].  Sets .loss_lpips, .loss_l2, .vec_loss like
+    the reference.  Inputs may be numpy, torch (CPU / ROCm) or DeviceArray; the result is a numpy
+    float32 vector, or a torch tensor on the input's device when x_hat is a torch tensor.
+    'l2' is exact-integer on the 8-bit lattice; unlike the reference it does not
+    build an LPIPS model it never uses (utils.py:157)."""
+
+    def __init__(self, distance, if_norm_reg=False, ctx=None):
+        if distance not in ("l2", "l2-lpips"):
+            raise ValueError("distance must be 'l2' or 'l2-lpips'")
+        self.distance = distance
+        self.if_norm_reg = if_norm_reg
+        self._ctx = ctx
+        if distance == "l2":
+            print("Use distance: l2")
+        else:
+            print("Use distance: lpips + l2")
+            raise NotImplementedError("'l2-lpips' needs the LPIPS/VGG16 kernels, which are not part of this round")
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = Context.get()
+        return self._ctx
+
+    def forward(self, x_hat, x_gt):
+        ctx = self.ctx
+        a = prepare_images(ctx, x_hat)
+        g = prepare_images(ctx, x_gt)
+        if a.shape[1] != g.shape[1]:
+            raise ValueError("image sizes differ")
+        out = ctx.empty((max(a.shape[0], 1),), np.float32)
+        check(ctx.lib.gl_l2_rows_u8(ctx.handle, _p(a.ptr), a.shape[0], _p(g.ptr), g.shape[0], a.shape[1], _p(out.ptr)))
+        l2 = out.numpy()[:a.shape[0]]
+        if type(x_hat).__module__.startswith("torch"):
+            import torch
+            l2 = torch.from_numpy(l2).to(x_hat.device)
+        self.loss_lpips = 0.0
+        self.loss_l2 = l2
+        self.vec_loss = 0.2 * self.loss_lpips + self.loss_l2     # utils.py:176
+        return self.vec_loss
+
+    __call__ = forward

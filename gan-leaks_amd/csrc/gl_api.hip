@@ -1,0 +1,166 @@
+// Context, memory and event entry points of the C ABI (include/ganleaks.h).
+#include "gl_common.h"
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void gl_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int gl_abi_version(void) { return GL_ABI_VERSION; }
+const char *gl_last_error(void) { return g_err; }
+
+int gl_device_count(int *out_count)
+{
+    GL_REQUIRE(out_count, "gl_device_count: NULL out_count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
+    *out_count = n;
+    return GL_OK;
+}
+
+int gl_ctx_create(int device, gl_ctx **out_ctx)
+{
+    GL_REQUIRE(out_ctx, "gl_ctx_create: NULL out_ctx");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        gl_set_error("gl_ctx_create: no HIP device visible (this library has no CPU fallback)");
+        return GL_ERR_NO_DEVICE;
+    }
+    GL_REQUIRE(device >= 0 && device < n, "gl_ctx_create: device %d out of range [0,%d)", device, n);
+    GL_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GL_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        gl_set_error("gl_ctx_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return GL_ERR_NO_DEVICE;
+    }
+    gl_ctx *c = new gl_ctx();
+    c->device = device;
+    GL_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    GL_HIP(hipMalloc((void **)&c->zero_page, 4096));
+    GL_HIP(hipMemsetAsync(c->zero_page, 0, 4096, c->stream));
+    GL_HIP(hipStreamSynchronize(c->stream));
+    *out_ctx = c;
+    return GL_OK;
+}
+
+int gl_ctx_destroy(gl_ctx *ctx)
+{
+    if (!ctx) return GL_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->zero_page);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return GL_OK;
+}
+
+int gl_ctx_set_stream(gl_ctx *ctx, void *hip_stream)
+{
+    GL_REQUIRE(ctx, "gl_ctx_set_stream: NULL ctx");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return GL_OK;
+}
+
+int gl_ctx_get_stream(gl_ctx *ctx, void **out_hip_stream)
+{
+    GL_REQUIRE(ctx && out_hip_stream, "gl_ctx_get_stream: NULL argument");
+    *out_hip_stream = (void *)ctx->stream;
+    return GL_OK;
+}
+
+int gl_ctx_sync(gl_ctx *ctx)
+{
+    GL_REQUIRE(ctx, "gl_ctx_sync: NULL ctx");
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev)
+{
+    GL_REQUIRE(ctx && out_dev, "gl_malloc: NULL argument");
+    GL_HIP(hipSetDevice(ctx->device));
+    *out_dev = nullptr;
+    if (bytes == 0) return GL_OK;
+    GL_HIP(hipMalloc(out_dev, bytes));
+    return GL_OK;
+}
+
+int gl_free(gl_ctx *ctx, void *dev)
+{
+    GL_REQUIRE(ctx, "gl_free: NULL ctx");
+    if (!dev) return GL_OK;
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    GL_HIP(hipFree(dev));
+    return GL_OK;
+}
+
+int gl_memcpy_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    GL_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), "gl_memcpy_h2d: NULL argument");
+    if (bytes == 0) return GL_OK;
+    GL_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int gl_memcpy_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    GL_REQUIRE(ctx && (bytes == 0 || (dst_host && src_dev)), "gl_memcpy_d2h: NULL argument");
+    if (bytes == 0) return GL_OK;
+    GL_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int gl_memset(gl_ctx *ctx, void *dev, int value, size_t bytes)
+{
+    GL_REQUIRE(ctx && (bytes == 0 || dev), "gl_memset: NULL argument");
+    if (bytes == 0) return GL_OK;
+    GL_HIP(hipMemsetAsync(dev, value, bytes, ctx->stream));
+    return GL_OK;
+}
+
+int gl_event_create(void **out_event)
+{
+    GL_REQUIRE(out_event, "gl_event_create: NULL out_event");
+    hipEvent_t e;
+    GL_HIP(hipEventCreate(&e));
+    *out_event = (void *)e;
+    return GL_OK;
+}
+
+int gl_event_destroy(void *event)
+{
+    if (!event) return GL_OK;
+    GL_HIP(hipEventDestroy((hipEvent_t)event));
+    return GL_OK;
+}
+
+int gl_event_record(gl_ctx *ctx, void *event)
+{
+    GL_REQUIRE(ctx && event, "gl_event_record: NULL argument");
+    GL_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
+    return GL_OK;
+}
+
+int gl_event_elapsed_ms(void *start, void *stop, float *out_ms)
+{
+    GL_REQUIRE(start && stop && out_ms, "gl_event_elapsed_ms: NULL argument");
+    GL_HIP(hipEventSynchronize((hipEvent_t)stop));
+    GL_HIP(hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GL_OK;
+}
+
+}  // extern "C"

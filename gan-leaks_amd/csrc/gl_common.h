@@ -1,0 +1,62 @@
+// Internal definitions shared by the HIP translation units of libganleaks_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/ganleaks.h"
+
+struct gl_ctx {
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;      // the stream work is enqueued on (own_stream or the caller's)
+    float *zero_page;        // 4 KiB of zeros on the device: source for out-of-image taps
+};
+
+void gl_set_error(const char *fmt, ...);
+
+#define GL_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            gl_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GL_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define GL_REQUIRE(cond, ...)                                                                \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            gl_set_error(__VA_ARGS__);                                                       \
+            return GL_ERR_INVALID;                                                           \
+        }                                                                                    \
+    } while (0)
+
+#define GL_LAUNCH_CHECK()                                                                    \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) {                                                              \
+            gl_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GL_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+static inline int64_t gl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// XCD-aware block id remap (8 XCDs, blocks are dealt round-robin): gives every XCD a contiguous
+// chunk of the logical grid so blocks sharing an operand panel share an L2.  Bijective for any nwg.
+__device__ __forceinline__ unsigned gl_xcd_remap(unsigned bid, unsigned nwg)
+{
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    const unsigned start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return start + (bid >> 3);
+}
+
+typedef __attribute__((address_space(1))) const void *gl_gptr;
+typedef __attribute__((address_space(3))) void *gl_lptr;
+
+// async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
+__device__ __forceinline__ void gl_glds16(const void *src, void *lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gl_gptr)src, (gl_lptr)lds_wave_base, 16, 0, 0);
+}

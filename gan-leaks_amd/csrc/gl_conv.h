@@ -1,0 +1,35 @@
+// Tap-gather implicit GEMM on the fp32 matrix cores: one kernel template for every dense
+// convolution shape on the path (ConvTranspose2d k4 s1 p0 on a 1x1 input, the four sub-pixel
+// phases of ConvTranspose2d k4 s2 p1, and -- later rounds -- 3x3 p1 convolutions).
+#pragma once
+#include "gl_common.h"
+
+struct GlGatherConv {
+    // input activations, NHWC fp32: [n_img][H][W][Cin]
+    const float *in;
+    int64_t positions;          // n_img * H * W   (GEMM M: one row per base-grid position)
+    int H, W, Cin;
+    // packed weights: [phases][cols_pad][K] fp32, K = ntaps * Cin contiguous
+    const float *wpack;
+    int cols;                   // real GEMM columns (output channels per position)
+    int cols_pad;               // multiple of 128
+    int ntaps;
+    // per phase: taps packed 2 bits each (value+1) -> input offset (dy,dx) in {-1,0,1}
+    uint32_t tap_dy[4], tap_dx[4];
+    // output, NHWC fp32: [n_img][Ho][Wo][cols]; position (y,x) of phase p writes (y*omul+oy[p], x*omul+ox[p])
+    float *out;
+    int Ho, Wo, omul;
+    int oy[4], ox[4];
+    // epilogue: v = acc * scale[c % cmod] + shift[c % cmod]; act 0 none, 1 relu
+    const float *scale, *shift;
+    int cmod;
+    int act;
+    const float *zero;          // >= 16 B of zeros (source of out-of-image taps)
+};
+
+int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
+
+// ConvTranspose2d(Cin -> 3, k4 s2 p1) + bias + tanh (+ 8-bit quantisation), VALU kernel.
+// in: NHWC [n][H][W][Cin]; w: reference layout [Cin][3][4][4]; out_f32 / out_u8: NCHW [n][3][2H][2W], either may be NULL.
+int gl_launch_convt_rgb_tanh(gl_ctx *ctx, const float *in, int64_t n_img, int H, int W, int Cin, const float *w, const float *bias,
+                             float *out_f32, uint8_t *out_u8);

@@ -1,0 +1,247 @@
+// DCGAN / WGAN-GP generator behind the C ABI: weight repacking (host) + the layer schedule.
+//   gan_models/dcgan/model_torch.py:75-96  Generator(z_dim, channels_img, features_g)
+//   gan_models/wgangp/model.py:37-58       identical graph and state_dict keys
+// Layer l = 0..3: ConvTranspose2d(bias=False) -> BatchNorm2d (eval: running stats) -> ReLU
+// Layer 4:        ConvTranspose2d(+bias) -> tanh           (-> 8-bit code of the generate branch)
+// Activations are NHWC fp32 and stay resident in HBM for a whole pass of `chunk` images.
+#include "gl_conv.h"
+#include <cmath>
+#include <vector>
+
+struct gl_dcgan {
+    gl_ctx *ctx;
+    int z_dim, z_pad, nc, fg;
+    int cin[5], cout[5];
+    float *wpack[5];           // device, packed
+    float *scale[4], *shift[4];
+    float *bias_out;
+    bool have_w[5], have_bn[4], have_bias;
+    int64_t chunk, ws_chunk;   // requested / allocated images per pass
+    float *ws_z, *ws_a[4];     // z padded; outputs of layers 0..3
+};
+
+namespace {
+
+__global__ void pad_rows_kernel(const float *__restrict__ in, int64_t n, int d, int dpad, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dpad) return;
+    const int64_t r = i / dpad;
+    const int c = (int)(i - r * dpad);
+    out[i] = c < d ? in[r * d + c] : 0.0f;
+}
+
+// sub-pixel decomposition of ConvTranspose2d(k=4, s=2, p=1): output row 2y+py receives
+//   py=0: ky=1 from input row y, ky=3 from y-1;   py=1: ky=0 from y+1, ky=2 from y.
+const int kKy[2][2] = {{1, 3}, {0, 2}};
+const int kDy[2][2] = {{0, -1}, {1, 0}};
+
+int upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
+{
+    if (!*dev) GL_HIP(hipMalloc((void **)dev, host.size() * sizeof(float)));
+    GL_HIP(hipMemcpyAsync(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int ensure_workspace(gl_dcgan *g, int64_t n)
+{
+    int64_t want = g->chunk > 0 ? g->chunk : 4096;
+    if (n < want) want = n;
+    if (want <= g->ws_chunk) return GL_OK;
+    GL_HIP(hipStreamSynchronize(g->ctx->stream));
+    (void)hipFree(g->ws_z);
+    g->ws_z = nullptr;
+    for (int l = 0; l < 4; ++l) { (void)hipFree(g->ws_a[l]); g->ws_a[l] = nullptr; }
+    g->ws_chunk = 0;
+    GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
+    int hw = 16;
+    for (int l = 0; l < 4; ++l) {
+        GL_HIP(hipMalloc((void **)&g->ws_a[l], (size_t)want * hw * g->cout[l] * 4));
+        hw *= 4;
+    }
+    g->ws_chunk = want;
+    return GL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl_dcgan **out)
+{
+    GL_REQUIRE(ctx && out, "gl_dcgan_create: NULL argument");
+    GL_REQUIRE(z_dim > 0 && z_dim <= 4096, "gl_dcgan_create: z_dim=%d unsupported", z_dim);
+    GL_REQUIRE(channels_img == 3, "gl_dcgan_create: channels_img=%d unsupported (the RGB tail kernel writes 3 channels)", channels_img);
+    GL_REQUIRE(features_g > 0 && features_g % 8 == 0, "gl_dcgan_create: features_g=%d must be a multiple of 8", features_g);
+    gl_dcgan *g = new gl_dcgan();
+    g->ctx = ctx;
+    g->z_dim = z_dim;
+    g->z_pad = (int)gl_ceil_div(z_dim, 32) * 32;
+    g->nc = channels_img;
+    g->fg = features_g;
+    const int ch[6] = {z_dim, features_g * 16, features_g * 8, features_g * 4, features_g * 2, channels_img};
+    for (int l = 0; l < 5; ++l) { g->cin[l] = ch[l]; g->cout[l] = ch[l + 1]; g->wpack[l] = nullptr; g->have_w[l] = false; }
+    for (int l = 0; l < 4; ++l) { g->scale[l] = g->shift[l] = nullptr; g->have_bn[l] = false; g->ws_a[l] = nullptr; }
+    g->bias_out = nullptr;
+    g->have_bias = false;
+    g->chunk = 0;
+    g->ws_chunk = 0;
+    g->ws_z = nullptr;
+    *out = g;
+    return GL_OK;
+}
+
+int gl_dcgan_destroy(gl_dcgan *g)
+{
+    if (!g) return GL_OK;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    for (int l = 0; l < 5; ++l) (void)hipFree(g->wpack[l]);
+    for (int l = 0; l < 4; ++l) { (void)hipFree(g->scale[l]); (void)hipFree(g->shift[l]); (void)hipFree(g->ws_a[l]); }
+    (void)hipFree(g->bias_out);
+    (void)hipFree(g->ws_z);
+    delete g;
+    return GL_OK;
+}
+
+int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass)
+{
+    GL_REQUIRE(g && images_per_pass >= 0, "gl_dcgan_set_chunk: bad argument");
+    g->chunk = images_per_pass;
+    return GL_OK;
+}
+
+int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
+{
+    GL_REQUIRE(g && w && layer >= 0 && layer < 5, "gl_dcgan_set_conv_weight: bad argument");
+    const int ci_n = g->cin[layer], co_n = g->cout[layer];
+    auto W = [&](int ci, int co, int ky, int kx) { return w[(((int64_t)ci * co_n + co) * 4 + ky) * 4 + kx]; };
+    std::vector<float> pk;
+    if (layer == 0) {
+        // 1x1 input: a plain GEMM [n][z_pad] x [16*C1][z_pad]^T, column = (ky*4+kx)*C1 + co  (NHWC 4x4xC1)
+        const int K = g->z_pad, cols = 16 * co_n, cols_pad = (int)gl_ceil_div(cols, 128) * 128;
+        pk.assign((size_t)cols_pad * K, 0.0f);
+        for (int ky = 0; ky < 4; ++ky)
+            for (int kx = 0; kx < 4; ++kx)
+                for (int co = 0; co < co_n; ++co)
+                    for (int ci = 0; ci < ci_n; ++ci) pk[((size_t)(ky * 4 + kx) * co_n + co) * K + ci] = W(ci, co, ky, kx);
+    } else if (layer < 4) {
+        // four phases x four taps; [phase][co_pad][tap*Cin + ci]
+        const int K = 4 * ci_n, cols_pad = (int)gl_ceil_div(co_n, 128) * 128;
+        pk.assign((size_t)4 * cols_pad * K, 0.0f);
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px)
+                for (int ty = 0; ty < 2; ++ty)
+                    for (int tx = 0; tx < 2; ++tx) {
+                        const int ky = kKy[py][ty], kx = kKy[px][tx], tap = ty * 2 + tx, phase = py * 2 + px;
+                        for (int co = 0; co < co_n; ++co) {
+                            float *dst = &pk[((size_t)phase * cols_pad + co) * K + (size_t)tap * ci_n];
+                            for (int ci = 0; ci < ci_n; ++ci) dst[ci] = W(ci, co, ky, kx);
+                        }
+                    }
+    } else {
+        pk.assign(w, w + (size_t)ci_n * co_n * 16);   // tail kernel reads the reference layout directly
+    }
+    int rc = upload(g->ctx, &g->wpack[layer], pk);
+    if (rc != GL_OK) return rc;
+    g->have_w[layer] = true;
+    return GL_OK;
+}
+
+int gl_dcgan_set_bn(gl_dcgan *g, int layer, const float *gamma, const float *beta, const float *mean, const float *var, float eps)
+{
+    GL_REQUIRE(g && gamma && beta && mean && var && layer >= 0 && layer < 4, "gl_dcgan_set_bn: bad argument");
+    const int c = g->cout[layer];
+    std::vector<float> sc(c), sh(c);
+    for (int i = 0; i < c; ++i) {
+        // y = (x - mean) / sqrt(var + eps) * gamma + beta  (nn.BatchNorm2d, eval)  ==  x * sc + sh
+        const double s = (double)gamma[i] / std::sqrt((double)var[i] + (double)eps);
+        sc[i] = (float)s;
+        sh[i] = (float)((double)beta[i] - (double)mean[i] * s);
+    }
+    int rc = upload(g->ctx, &g->scale[layer], sc);
+    if (rc != GL_OK) return rc;
+    rc = upload(g->ctx, &g->shift[layer], sh);
+    if (rc != GL_OK) return rc;
+    g->have_bn[layer] = true;
+    return GL_OK;
+}
+
+int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias)
+{
+    GL_REQUIRE(g && bias, "gl_dcgan_set_out_bias: bad argument");
+    std::vector<float> b(bias, bias + g->nc);
+    int rc = upload(g->ctx, &g->bias_out, b);
+    if (rc != GL_OK) return rc;
+    g->have_bias = true;
+    return GL_OK;
+}
+
+int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev)
+{
+    GL_REQUIRE(g && n >= 0, "gl_dcgan_forward: bad argument");
+    for (int l = 0; l < 5; ++l)
+        if (!g->have_w[l] || (l < 4 && !g->have_bn[l])) {
+            gl_set_error("gl_dcgan_forward: weights of layer %d not loaded", l);
+            return GL_ERR_STATE;
+        }
+    if (!g->have_bias) { gl_set_error("gl_dcgan_forward: gen.4.bias not loaded"); return GL_ERR_STATE; }
+    if (n == 0) return GL_OK;
+    GL_REQUIRE(z_dev && (out_f32_dev || out_u8_dev), "gl_dcgan_forward: NULL z or no output requested");
+    gl_ctx *ctx = g->ctx;
+    int rc = ensure_workspace(g, n);
+    if (rc != GL_OK) return rc;
+    const int64_t img_elems = (int64_t)g->nc * 64 * 64;
+
+    for (int64_t i0 = 0; i0 < n; i0 += g->ws_chunk) {
+        const int64_t m = (n - i0 < g->ws_chunk) ? n - i0 : g->ws_chunk;
+        {
+            const int64_t tot = m * g->z_pad;
+            hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)gl_ceil_div(tot, 256)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim,
+                               g->z_pad, g->ws_z);
+            GL_LAUNCH_CHECK();
+        }
+        // layer 0: ConvT k4 s1 p0 on 1x1 -> 4x4xC1 (one GEMM), BN + ReLU
+        {
+            GlGatherConv p = {};
+            p.in = g->ws_z; p.positions = m; p.H = 1; p.W = 1; p.Cin = g->z_pad;
+            p.wpack = g->wpack[0]; p.cols = 16 * g->cout[0]; p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128; p.ntaps = 1;
+            p.tap_dy[0] = 1; p.tap_dx[0] = 1;   // offset 0
+            p.out = g->ws_a[0]; p.Ho = 1; p.Wo = 1; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0;
+            p.scale = g->scale[0]; p.shift = g->shift[0]; p.cmod = g->cout[0]; p.act = 1; p.zero = ctx->zero_page;
+            rc = gl_launch_gather_conv(ctx, p, 1);
+            if (rc != GL_OK) return rc;
+        }
+        // layers 1..3: ConvT k4 s2 p1 as four 2x2-tap sub-pixel convolutions, BN + ReLU
+        int hw = 4;
+        for (int l = 1; l < 4; ++l) {
+            GlGatherConv p = {};
+            p.in = g->ws_a[l - 1]; p.positions = m * hw * hw; p.H = hw; p.W = hw; p.Cin = g->cin[l];
+            p.wpack = g->wpack[l]; p.cols = g->cout[l]; p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128; p.ntaps = 4;
+            for (int py = 0; py < 2; ++py)
+                for (int px = 0; px < 2; ++px) {
+                    uint32_t dy = 0, dx = 0;
+                    for (int ty = 0; ty < 2; ++ty)
+                        for (int tx = 0; tx < 2; ++tx) {
+                            const int tap = ty * 2 + tx;
+                            dy |= (uint32_t)(kDy[py][ty] + 1) << (2 * tap);
+                            dx |= (uint32_t)(kDy[px][tx] + 1) << (2 * tap);
+                        }
+                    p.tap_dy[py * 2 + px] = dy; p.tap_dx[py * 2 + px] = dx;
+                    p.oy[py * 2 + px] = py; p.ox[py * 2 + px] = px;
+                }
+            p.out = g->ws_a[l]; p.Ho = 2 * hw; p.Wo = 2 * hw; p.omul = 2;
+            p.scale = g->scale[l]; p.shift = g->shift[l]; p.cmod = g->cout[l]; p.act = 1; p.zero = ctx->zero_page;
+            rc = gl_launch_gather_conv(ctx, p, 4);
+            if (rc != GL_OK) return rc;
+            hw *= 2;
+        }
+        // layer 4: ConvT k4 s2 p1 -> 3 channels, + bias, tanh, (quantise)
+        rc = gl_launch_convt_rgb_tanh(ctx, g->ws_a[3], m, hw, hw, g->cin[4], g->wpack[4], g->bias_out,
+                                      out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr, out_u8_dev ? out_u8_dev + i0 * img_elems : nullptr);
+        if (rc != GL_OK) return rc;
+    }
+    return GL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+/* ganleaks.h -- C ABI of libganleaks_hip.so (MI355X / gfx950).
+ *
+ * The reference (CarloSaccardi/GAN-Leaks) is pure Python and has no FFI of its own; the drop-in
+ * boundary for its full-black-box attack path is the set of Python call signatures listed in
+ * SURVEY.md 8(b).  Each entry point below names the reference interface it stands behind
+ * (file:line relative to the reference tree).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative gl_status on failure and never throws;
+ *     gl_last_error() returns a thread-local, NUL-terminated description of the last failure.
+ *   - plain pointers and sizes only.  Pointers named *_dev are DEVICE pointers (hipMalloc'd by the
+ *     caller, by gl_malloc, or by PyTorch-ROCm: tensor.data_ptr()); *_host are host pointers.
+ *   - one gl_ctx per GPU per host thread; all work of a context is enqueued on its HIP stream
+ *     (private by default, or the caller's via gl_ctx_set_stream) and is asynchronous unless the
+ *     function says it synchronises.
+ *   - image rows are C-contiguous [count][D] with D = C*H*W in the reference's NCHW order
+ *     (attack_models/fbb.py:134-135).
+ */
+#ifndef GANLEAKS_H
+#define GANLEAKS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GL_ABI_VERSION 1
+
+typedef enum gl_status {
+    GL_OK = 0,
+    GL_ERR_INVALID = -1,   /* bad argument (NULL, negative size, unsupported shape) */
+    GL_ERR_HIP = -2,       /* a HIP runtime call failed */
+    GL_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    GL_ERR_STATE = -4,     /* object not ready (weights missing, bank not set) */
+    GL_ERR_EMPTY_BANK = -5 /* bank shorter than one BATCH_SIZE: reference raises ValueError at fbb.py:83 */
+} gl_status;
+
+typedef struct gl_ctx gl_ctx;       /* opaque: device + stream + scratch */
+typedef struct gl_dcgan gl_dcgan;   /* opaque: packed DCGAN / WGAN-GP generator */
+
+/* ---------------------------------------------------------------- library / context */
+int gl_abi_version(void);
+const char *gl_last_error(void);
+int gl_device_count(int *out_count);
+int gl_ctx_create(int device, gl_ctx **out_ctx);           /* replaces `device = torch.device("cuda")`, fbb.py:40 */
+int gl_ctx_destroy(gl_ctx *ctx);
+int gl_ctx_set_stream(gl_ctx *ctx, void *hip_stream);      /* NULL restores the private stream */
+int gl_ctx_get_stream(gl_ctx *ctx, void **out_hip_stream);
+int gl_ctx_sync(gl_ctx *ctx);                              /* hipStreamSynchronize */
+
+/* device memory + copies (synchronous w.r.t. the context stream) */
+int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev);
+int gl_free(gl_ctx *ctx, void *dev);
+int gl_memcpy_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* `.to(device)`, fbb.py:135,141,145 */
+int gl_memcpy_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* `.item()`, fbb.py:88 */
+int gl_memset(gl_ctx *ctx, void *dev, int value, size_t bytes);
+
+/* HIP events on the context stream (bench.py timing) */
+int gl_event_create(void **out_event);
+int gl_event_destroy(void *event);
+int gl_event_record(gl_ctx *ctx, void *event);
+int gl_event_elapsed_ms(void *start, void *stop, float *out_ms);   /* synchronises on `stop` */
+
+/* ---------------------------------------------------------------- 8-bit image codec */
+/* float images in [-1,1] -> u8 codes, exactly when x == fl32(2*(u/255.)-1)
+ * (attack_models/utils.py:82 followed by fbb.py:134 `.float()`).  *off_lattice_dev (int32, device,
+ * caller-zeroed) is incremented for every element that is not on that lattice. */
+int gl_encode_lattice_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev);
+/* u8 -> float32 2*(u/255.)-1 (float64 arithmetic, utils.py:82) */
+int gl_decode_u8(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev);
+/* generator output -> u8 as the generate branches write it: mode 0 = Normalize(-1,2) then
+ * ToPILImage mul(255).byte() (gan_models/dcgan/train_torch.py:154-158,172); mode 1 = x*0.5+0.5
+ * (gan_models/pggan/train.py:238). */
+int gl_quantize_f32(gl_ctx *ctx, const float *x_dev, int64_t count, int mode, uint8_t *u8_dev);
+
+/* ---------------------------------------------------------------- L2 nearest neighbour (the hot path) */
+/* bytes one prepared row occupies: D rounded up to the kernel's K tile */
+int64_t gl_l2_row_stride(int64_t d);
+/* u8 rows -> biased int8 rows (u-128, zero padded to gl_l2_row_stride(d)) and per-row sum (u-128)^2.
+ * rows_i8_dev: [count][gl_l2_row_stride(d)] bytes; norms_dev: [count] int32. */
+int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_t d, int8_t *rows_i8_dev, int32_t *norms_dev);
+/* keys[q] = UINT64_MAX */
+int gl_keys_init(gl_ctx *ctx, uint64_t *keys_dev, int64_t nq);
+/* keys[q] = min(keys[q], (S(q,n) << 32) | (index_base + n)) over n in [0, n_rows):
+ *   S = sum_k (uq_k - ub_k)^2, exact in int32.   Replaces the loop body + torch.min of custom_knn
+ *   (attack_models/fbb.py:77-86) with Loss('l2') (attack_models/utils.py:163,169,176) for the whole
+ *   query set at once.  The caller applies the BATCH_SIZE truncation (fbb.py:77) by passing
+ *   n_rows = n_eff.  index_base is the global index of bank row 0 (bank shards). */
+int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_norm_dev, int64_t n_rows, int64_t index_base,
+                 const int8_t *query_i8_dev, const int32_t *query_norm_dev, int64_t nq, int64_t d, uint64_t *keys_dev);
+/* keys -> (distance fp32 = fl32(S * 4/(255^2 d)), index int64).  `min_distance.item(), indices[min_index].item()`, fbb.py:88 */
+int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d, float *dist_dev, int64_t *idx_dev);
+
+/* out[i] = fl32(S(x_hat[i], x_gt[b_gt == 1 ? 0 : i]) * 4/(255^2 d)), i < b: the per-sample loss vector
+ * Loss('l2').forward(x_hat, x_gt) returns (attack_models/utils.py:163,169,171-177; x_gt broadcasts
+ * when it holds one image, fbb.py:79).  u8 rows on the device. */
+int gl_l2_rows_u8(gl_ctx *ctx, const uint8_t *x_hat_u8_dev, int64_t b, const uint8_t *x_gt_u8_dev, int64_t b_gt, int64_t d, float *out_dev);
+
+/* One-call form for host callers: u8 images in HOST memory, results in HOST memory; applies the
+ * truncation n_eff = (n_bank / batch_size) * batch_size itself.  Equals
+ * [custom_knn(bank, q, Loss('l2'), args) for q in queries]  (attack_models/fbb.py:73-88,156-159).
+ * Synchronises. Returns GL_ERR_EMPTY_BANK when n_bank < batch_size. */
+int gl_fbb_knn_l2_host(gl_ctx *ctx, const uint8_t *bank_u8_host, int64_t n_bank, const uint8_t *queries_u8_host, int64_t nq,
+                       int64_t d, int64_t batch_size, float *dist_host, int64_t *idx_host);
+
+/* ---------------------------------------------------------------- DCGAN / WGAN-GP generator */
+/* gan_models/dcgan/model_torch.py:75-96 == gan_models/wgangp/model.py:37-58:
+ * 4 x [ConvTranspose2d(k4, bias=False) -> BatchNorm2d(eval) -> ReLU] (s1p0 then s2p1 x3),
+ * ConvTranspose2d(k4,s2,p1)+bias -> tanh.  Output 64x64. */
+int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl_dcgan **out);
+int gl_dcgan_destroy(gl_dcgan *g);
+/* weights in the reference's state_dict layouts, HOST pointers (PyTorch only reads the .pth):
+ * layer 0..3: gen.{layer}.0.weight [C_in][C_out][4][4]; layer 4: gen.4.weight */
+int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w_host);
+/* gen.{layer}.1.{weight,bias,running_mean,running_var}, eps = 1e-5 (nn.BatchNorm2d default) */
+int gl_dcgan_set_bn(gl_dcgan *g, int layer, const float *gamma_host, const float *beta_host, const float *mean_host,
+                    const float *var_host, float eps);
+int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias_host);   /* gen.4.bias */
+/* z_dev [n][z_dim] fp32.  Either output may be NULL: out_f32_dev [n][C][64][64] (what
+ * Generator.forward returns) and out_u8_dev [n][C][64][64] (the PNG bytes of the generate branch,
+ * quantised as gl_quantize_f32 mode 0). */
+int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev);
+/* images per internal pass (activations for that many images stay resident); 0 = default */
+int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANLEAKS_H */

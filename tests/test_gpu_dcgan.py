@@ -1,0 +1,130 @@
+"""GPU parity tests of the DCGAN / WGAN-GP generator stack (fp32 matrix-core kernels) against the
+reference Generator's outputs (tests/golden/dcgan_gen.npz) and the numpy oracle.
+Tolerance: 2e-5 absolute on the tanh output in (-1,1) (fp32 arithmetic, different summation
+order; north_star allows 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import ganleaks_amd
+    return ganleaks_amd
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "dcgan_gen.npz"))
+
+
+def test_generator_matches_reference(gl, synth, golden):
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    from ganleaks_amd.gan_models.wgangp.model import Generator as WGenerator
+    sd = synth.dcgan_state_dict(int(golden["weight_seed"]))
+    z = synth.latent(int(golden["z_seed"]), int(golden["n"]))
+    for cls, key in ((Generator, "out"), (WGenerator, "out_wgangp")):
+        g = cls(100, 3, 64)
+        assert "matched" in g.load_state_dict(sd)
+        out = g.eval()(z)
+        assert out.shape == (8, 3, 64, 64) and out.dtype == np.float32
+        err = np.abs(out - golden[key]).max()
+        assert err < ATOL, err
+
+
+def test_torch_tensors_and_stack(gl, synth, golden):
+    import torch
+    from ganleaks_amd.gan_models.dcgan.model_torch import stackGenerators
+    z = synth.latent(int(golden["z_seed"]), int(golden["n"]))
+    sd = {}
+    for gi in range(2):
+        s = synth.dcgan_state_dict(int(golden["weight_seed"]) + gi, prefix=f"gen.{gi}.gen.")
+        sd.update({k: torch.from_numpy(np.asarray(v)) for k, v in s.items()})
+    st = stackGenerators(100, 3, 64, 2)
+    st.load_state_dict(sd)
+    o0 = st(torch.from_numpy(z), 0)
+    o1 = st(torch.from_numpy(z), 1)
+    assert isinstance(o0, torch.Tensor)
+    assert np.abs(o0.numpy() - golden["out"]).max() < ATOL
+    assert np.abs(o1.numpy() - golden["stack_out_g1"]).max() < ATOL
+
+
+def test_bank_codes_and_chunking(gl, synth, oracle, golden):
+    """generate_u8 == quantise(forward) bit for bit; results independent of the pass size; the codes
+    agree with the reference-derived ones except where fp32 rounding straddles a code boundary"""
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(int(golden["weight_seed"]))
+    g = Generator(100, 3, 64)
+    g.load_state_dict(sd)
+    z = synth.latent(5, 300)
+    f32, u8 = g.forward_device(z, True, True)
+    f = f32.numpy()
+    u = u8.numpy()
+    assert np.array_equal(u, oracle.quantize_to_u8(f))
+    g2 = Generator(100, 3, 64)
+    g2.load_state_dict(sd)
+    g2.set_chunk(64)                      # 300 = 4 * 64 + 44: ragged last pass
+    f2 = g2(z)
+    assert np.array_equal(f2, f)
+    # against the oracle's float64 forward on a few images
+    zo = z[:3]
+    ref = oracle.dcgan_generator_forward(sd, zo)
+    assert np.abs(f[:3] - ref).max() < ATOL
+    mism = np.mean(u[:3] != oracle.quantize_to_u8(ref))
+    assert mism < 2e-3, mism
+    assert np.abs(u[:3].astype(int) - oracle.quantize_to_u8(ref).astype(int)).max() <= 1
+
+
+def test_generator_errors(gl, synth):
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    g = Generator(100, 3, 64)
+    with pytest.raises(RuntimeError):
+        g(synth.latent(1, 2))
+    sd = synth.dcgan_state_dict(1)
+    del sd["gen.2.1.running_var"]
+    with pytest.raises(KeyError):
+        g.load_state_dict(sd)
+    with pytest.raises(gl.GanLeaksError):
+        Generator(100, 1, 64)._ensure()
+
+
+def test_small_features_g(gl, synth, oracle):
+    """features_g = 8 (the size the reference's own smoke block uses, model_torch.py:137)"""
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(9, z_dim=100, features_g=8)
+    g = Generator(100, 3, 8)
+    g.load_state_dict(sd)
+    z = synth.latent(2, 5)
+    out = g(z)
+    ref = oracle.dcgan_generator_forward(sd, z)
+    assert np.abs(out - ref).max() < ATOL
+
+
+def test_end_to_end_generator_bank_attack(gl, synth, oracle, coracle_mod):
+    """north_star path: z -> generator -> 8-bit bank (device resident) -> L2 1-NN"""
+    from ganleaks_amd.attack import Bank
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(1234)
+    g = Generator(100, 3, 64)
+    g.load_state_dict(sd)
+    bank_u8 = g.generate_u8(synth.latent(1, 1000))
+    host_bank = bank_u8.numpy()
+    pos = synth.perturb_u8(3, host_bank[[5, 77, 959, 990]], 4.0)
+    neg = synth.lowpass_u8_images(4, 4, 64)
+    q = np.concatenate([pos, neg])
+    dist, idx = gl.attack(q, bank_u8, batch_size=64)
+    od, oi, _ = coracle_mod.knn_l2_u8(host_bank, q, 64)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert idx[:3].tolist() == [5, 77, 959] and idx[3] != 990
+
+
+@pytest.fixture(scope="module")
+def coracle_mod():
+    import c_oracle
+    return c_oracle
