@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the fbb attack path on MI355X.
+
+Workload (BASELINE.json configs[1]): DCGAN-64 generator, 10 000 queries x 100 000-sample bank, L2.
+One "step" = one full pass of the hot path with z, weights and the query codes already resident in
+HBM:   z --fp32-MFMA generator--> 8-bit bank --prepare--> int8-MFMA pairwise L2 + argmin
+       [--RCCL min over ranks-->] (dist[Q], idx[Q]) on the host.
+value = queries / step time (whole job, all ranks).  N > 1 shards the bank (strong scaling: the
+problem is fixed), every rank keeps all queries, one all-reduce(min) of Q packed keys.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (fields: see the project brief); progress goes to stderr.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_GATHER_PER_IMG = 2.0 * (100 * 1024 * 16 + 16 * 1024 * 512 * 16 + 64 * 512 * 256 * 16 + 256 * 256 * 128 * 16)  # layers 0-3
+F_RGB_PER_IMG = 2.0 * (1024 * 128 * 3 * 16)                                                                       # layer 4
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_I8_MFMA_TOPS = 5000.0       # 2 x the ~2.5 PF bf16 dense peak (same cycles at twice the K)
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--bank", type=int, default=100000)
+    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--chunk", type=int, default=0, help="generator images per pass (0 = library default)")
+    ap.add_argument("--cpu-queries", type=int, default=16, help="queries timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--check-queries", type=int, default=64, help="queries checked against the oracle after the run")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed launcher (see module docstring)" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import ganleaks_amd as gl
+    from ganleaks_amd import shard
+    from ganleaks_amd._lib import check
+    from ganleaks_amd.attack_models.eval_roc import plot_roc
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = gl.Context.get(local_rank)
+    lib = ctx.lib
+    p = ctypes.c_void_p
+    synth = gl.synth
+
+    Q, N, B = args.queries, args.bank, args.batch_size
+    D = 3 * 64 * 64
+    bounds = shard.shard_bounds(N, B, world)
+    n_eff = bounds[-1]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    n_loc = hi - lo
+
+    # ---------------------------------------------------------------- setup (untimed)
+    t_setup = time.time()
+    sd = synth.dcgan_state_dict(1234)
+    gen = Generator(100, 3, 64, ctx)
+    gen.load_state_dict(sd)
+    if args.chunk:
+        gen.set_chunk(args.chunk)
+    z_all = synth.latent(1, N)                               # the bank's latents; bank index = z index
+    z_dev = ctx.to_device(z_all[lo:hi].reshape(n_loc, 100))
+    # queries: members = fresh generator samples + pixel noise, non-members = unrelated low-pass images
+    n_pos = Q // 2
+    pos_clean = gen.generate_u8(synth.latent(2, n_pos)).numpy()
+    pos = synth.perturb_u8(5, pos_clean, 0.05 * 127.5)
+    neg = synth.lowpass_u8_images(3, Q - n_pos, 64)
+    queries_u8 = np.concatenate([pos, neg])
+    q_dev = ctx.to_device(queries_u8.reshape(Q, D))
+    del pos_clean
+
+    stride = int(lib.gl_l2_row_stride(D))
+    bank_u8 = ctx.empty((n_loc, D), np.uint8)
+    bank_i8 = ctx.empty((n_loc, stride), np.int8)
+    bank_nrm = ctx.empty((n_loc,), np.int32)
+    q_i8 = ctx.empty((Q, stride), np.int8)
+    q_nrm = ctx.empty((Q,), np.int32)
+    keys = ctx.empty((Q,), np.uint64)
+    dist_dev = ctx.empty((Q,), np.float32)
+    idx_dev = ctx.empty((Q,), np.int64)
+    out_dist = np.empty(Q, np.float32)
+    out_idx = np.empty(Q, np.int64)
+    keys_t = None
+    if world > 1:
+        keys_t = torch.as_tensor(keys.view((Q,), np.int64), device="cuda:%d" % local_rank)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # one in-order stream for kernels + RCCL
+    log("[rank %d] setup %.1fs: bank rows [%d,%d) of n_eff=%d, %d queries" % (rank, time.time() - t_setup, lo, hi, n_eff, Q))
+
+    ev = [ctx.event() for _ in range(4)]
+
+    def step(timed_phases=None):
+        if timed_phases is not None:
+            ev[0].record()
+        check(lib.gl_dcgan_forward(gen._handle, p(z_dev.ptr), n_loc, p(0), p(bank_u8.ptr)))
+        if timed_phases is not None:
+            ev[1].record()
+        check(lib.gl_l2_prepare(ctx.handle, p(bank_u8.ptr), n_loc, D, p(bank_i8.ptr), p(bank_nrm.ptr)))
+        check(lib.gl_l2_prepare(ctx.handle, p(q_dev.ptr), Q, D, p(q_i8.ptr), p(q_nrm.ptr)))
+        check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
+        check(lib.gl_l2_knn_i8(ctx.handle, p(bank_i8.ptr), p(bank_nrm.ptr), n_loc, lo, p(q_i8.ptr), p(q_nrm.ptr), Q, D, p(keys.ptr)))
+        if timed_phases is not None:
+            ev[2].record()
+        if world > 1:
+            dist.all_reduce(keys_t, op=dist.ReduceOp.MIN)
+        check(lib.gl_keys_unpack(ctx.handle, p(keys.ptr), Q, D, p(dist_dev.ptr), p(idx_dev.ptr)))
+        check(lib.gl_memcpy_d2h(ctx.handle, out_dist.ctypes.data_as(p), p(dist_dev.ptr), Q * 4))
+        check(lib.gl_memcpy_d2h(ctx.handle, out_idx.ctypes.data_as(p), p(idx_dev.ptr), Q * 8))
+        if timed_phases is not None:
+            ev[3].record()
+            ctx.sync()
+            timed_phases["generator_ms"] += ev[0].elapsed_ms_until(ev[1])
+            timed_phases["distance_ms"] += ev[1].elapsed_ms_until(ev[2])
+            timed_phases["reduce_unpack_d2h_ms"] += ev[2].elapsed_ms_until(ev[3])
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    phases = {"generator_ms": 0.0, "distance_ms": 0.0, "reduce_unpack_d2h_ms": 0.0}
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(phases)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.prof_enable(False)
+    prof = ctx.prof_read()
+    ctx.prof_reset()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = Q / (elapsed / args.steps)
+
+    # ---------------------------------------------------------------- per-kernel rooflines (this rank's launches)
+    def kernel_entry(name, alg_per_step, bound, peak, unit, scale):
+        ms, launches = prof[name]
+        if launches == 0 or ms <= 0:
+            return None
+        per_launch = alg_per_step * args.steps / launches
+        avg_ms = ms / launches
+        achieved = per_launch / (avg_ms * 1e-3) / scale
+        return {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
+                "frac": round(achieved / peak, 4), "traffic": None, "launches": int(launches), "avg_ms": round(avg_ms, 4),
+                "alg_per_launch": per_launch}
+
+    kernels = [
+        kernel_entry("gather_conv", n_loc * F_GATHER_PER_IMG, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1e12),
+        kernel_entry("l2_knn", 2.0 * Q * n_loc * D, "mfma", PEAK_I8_MFMA_TOPS, "TOP/s", 1e12),
+        kernel_entry("convt_rgb", n_loc * F_RGB_PER_IMG, "valu", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1e12),
+        kernel_entry("l2_prepare", 2.0 * (n_loc + Q) * D, "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
+    ]
+    kernels = [k for k in kernels if k]
+    dominant = max(kernels, key=lambda k: k["avg_ms"] * k["launches"])
+    roofline = {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    roofline["kernel"] = dominant["kernel"]
+    roofline["avg_launch_ms"] = dominant["avg_ms"]
+    roofline["launches_per_step"] = dominant["launches"] / args.steps
+
+    # ---------------------------------------------------------------- parity check against the oracle (untimed)
+    parity = None
+    auroc = None
+    if args.check_queries > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import c_oracle
+        nchk = min(args.check_queries, Q)
+        sel = np.linspace(0, Q - 1, nchk).astype(np.int64)
+        _, oi, os_ = c_oracle.knn_l2_u8(bank_u8.numpy(), queries_u8[sel].reshape(nchk, D), 1)
+        okeys = (os_.astype(np.uint64) << np.uint64(32)) | (oi + lo).astype(np.uint64)
+        if world > 1:
+            tk = torch.from_numpy(okeys.view(np.int64)).cuda()
+            dist.all_reduce(tk, op=dist.ReduceOp.MIN)
+            okeys = tk.cpu().numpy().view(np.uint64)
+        o_idx = (okeys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        o_dist = ((okeys >> np.uint64(32)).astype(np.float64) * (4.0 / (65025.0 * D))).astype(np.float32)
+        parity = {"queries_checked": int(nchk), "idx_equal": bool(np.array_equal(o_idx, out_idx[sel])),
+                  "max_abs_dist_err": float(np.abs(o_dist.astype(np.float64) - out_dist[sel]).max())}
+    if rank == 0:
+        _, _, _, auc, ap_, prec = plot_roc(-out_dist[:n_pos].astype(np.float64), -out_dist[n_pos:].astype(np.float64))
+        auroc = {"auc": auc, "ap": ap_, "precision_at_-0.14": prec}
+
+    # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_queries > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import torch_port
+        nq_cpu = min(args.cpu_queries, Q)
+        sel = np.linspace(0, Q - 1, nq_cpu).astype(np.int64)
+        host_bank = bank_u8.numpy().reshape(n_loc, 3, 64, 64)
+        t_prep = time.time()
+        bank_f = torch_port.dequantize(host_bank)                 # what fbb.main builds (fbb.py:134-135)
+        q_f = torch_port.dequantize(queries_u8[sel])
+        log("[cpu] bank dequantised to fp32 in %.1fs; timing %d queries x %d samples on %d threads" %
+            (time.time() - t_prep, nq_cpu, n_loc, torch.get_num_threads()))
+        torch_port.custom_knn(bank_f[:6400], q_f[0], torch_port.l2_loss, B)      # warm-up
+        tc = time.perf_counter()
+        cd, ci = [], []
+        for k in range(nq_cpu):
+            d_, i_ = torch_port.custom_knn(bank_f, q_f[k], torch_port.l2_loss, B)
+            cd.append(d_)
+            ci.append(i_)
+        cpu_s = time.perf_counter() - tc
+        cpu = {"value": round(nq_cpu / cpu_s, 4), "unit": "query-images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+               "sample": "%d of the %d queries x the full %d-sample bank, BATCH_SIZE %d, PyTorch-CPU restatement of fbb.custom_knn "
+                         "(oracle/torch_port.py); bank search only, the CPU does not run the generator" % (nq_cpu, Q, n_loc, B),
+               "seconds": round(cpu_s, 2),
+               "idx_equal_gpu": bool(np.array_equal(np.array(ci), out_idx[sel])),
+               "max_abs_dist_diff_vs_gpu": float(np.abs(np.array(cd) - out_dist[sel]).max())}
+        del bank_f
+
+    if rank == 0:
+        line = {
+            "metric": "attack query-images/sec (10k queries x 100k samples) + AUROC delta vs ref",
+            "value": round(value, 2), "unit": "query-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (generator) + i8->i32 exact (distance)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)", "queries": Q, "bank": N,
+                       "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d, queries replicated, "
+                       "all-reduce(min) of %d packed keys" % (world, Q) if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+            "phases_ms_per_step_rank0": {k: round(v / args.steps, 3) for k, v in phases.items()},
+            "parity": parity,
+            "auroc": auroc,
+            "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

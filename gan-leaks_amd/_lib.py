@@ -51,6 +51,9 @@ SIGNATURES = {
     "gl_event_destroy": (_i, [_p]),
     "gl_event_record": (_i, [_p, _p]),
     "gl_event_elapsed_ms": (_i, [_p, _p, ctypes.POINTER(ctypes.c_float)]),
+    "gl_prof_enable": (_i, [_p, _i]),
+    "gl_prof_read": (_i, [_p, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
+    "gl_prof_reset": (_i, [_p]),
     "gl_encode_lattice_f32": (_i, [_p, _p, _i64, _p, _p]),
     "gl_decode_u8": (_i, [_p, _p, _i64, _p]),
     "gl_quantize_f32": (_i, [_p, _p, _i64, _i, _p]),
@@ -171,9 +174,26 @@ class Context:
             check(self.lib.gl_memcpy_h2d(self.handle, _p(a.ptr), host.ctypes.data_as(_p), a.nbytes))
         return a
 
-    # ---- events
+    # ---- events / per-kernel timing
     def event(self):
         return Event(self)
+
+    PROF_TAGS = {"gather_conv": 0, "l2_knn": 1, "convt_rgb": 2, "l2_prepare": 3}
+
+    def prof_enable(self, on=True):
+        check(self.lib.gl_prof_enable(self.handle, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.gl_prof_reset(self.handle))
+
+    def prof_read(self):
+        """{kernel: (total_ms, launches)} since the last reset (synchronises)."""
+        out = {}
+        for name, tag in self.PROF_TAGS.items():
+            ms, n = ctypes.c_double(0), _i64(0)
+            check(self.lib.gl_prof_read(self.handle, tag, ctypes.byref(ms), ctypes.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out
 
 
 class Event:

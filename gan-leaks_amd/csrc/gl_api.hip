@@ -12,7 +12,72 @@ void gl_set_error(const char *fmt, ...)
     va_end(ap);
 }
 
+static hipEvent_t prof_event(gl_ctx *c)
+{
+    if (!c->prof_pool.empty()) {
+        hipEvent_t e = c->prof_pool.back();
+        c->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+gl_prof_scope::gl_prof_scope(gl_ctx *c, int tag) : ctx(c), active(c && c->prof_on)
+{
+    if (!active) return;
+    span.tag = tag;
+    span.start = prof_event(c);
+    span.stop = prof_event(c);
+    (void)hipEventRecord(span.start, c->stream);
+}
+
+gl_prof_scope::~gl_prof_scope()
+{
+    if (!active) return;
+    (void)hipEventRecord(span.stop, ctx->stream);
+    ctx->prof_spans.push_back(span);
+}
+
 extern "C" {
+
+int gl_prof_enable(gl_ctx *ctx, int on)
+{
+    GL_REQUIRE(ctx, "gl_prof_enable: NULL ctx");
+    ctx->prof_on = on != 0;
+    return GL_OK;
+}
+
+int gl_prof_read(gl_ctx *ctx, int tag, double *out_total_ms, int64_t *out_launches)
+{
+    GL_REQUIRE(ctx && out_total_ms && out_launches, "gl_prof_read: NULL argument");
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    double total = 0.0;
+    int64_t n = 0;
+    for (const gl_prof_span &s : ctx->prof_spans)
+        if (s.tag == tag) {
+            float ms = 0.f;
+            GL_HIP(hipEventElapsedTime(&ms, s.start, s.stop));
+            total += ms;
+            ++n;
+        }
+    *out_total_ms = total;
+    *out_launches = n;
+    return GL_OK;
+}
+
+int gl_prof_reset(gl_ctx *ctx)
+{
+    GL_REQUIRE(ctx, "gl_prof_reset: NULL ctx");
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    for (const gl_prof_span &s : ctx->prof_spans) {
+        ctx->prof_pool.push_back(s.start);
+        ctx->prof_pool.push_back(s.stop);
+    }
+    ctx->prof_spans.clear();
+    return GL_OK;
+}
 
 int gl_abi_version(void) { return GL_ABI_VERSION; }
 const char *gl_last_error(void) { return g_err; }
@@ -46,6 +111,7 @@ int gl_ctx_create(int device, gl_ctx **out_ctx)
     }
     gl_ctx *c = new gl_ctx();
     c->device = device;
+    c->prof_on = false;
     GL_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     GL_HIP(hipMalloc((void **)&c->zero_page, 4096));
@@ -60,6 +126,8 @@ int gl_ctx_destroy(gl_ctx *ctx)
     if (!ctx) return GL_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)gl_prof_reset(ctx);
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->zero_page);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

@@ -234,6 +234,7 @@ int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_
     const int64_t waves_needed = count;
     int64_t blocks = gl_ceil_div(waves_needed, kThreads / 64);
     if (blocks > 4096) blocks = 4096;
+    gl_prof_scope prof_(ctx, GL_PROF_L2_PREPARE);
     hipLaunchKernelGGL(l2_prepare_kernel, dim3((int)blocks), dim3(kThreads), 0, ctx->stream, rows_u8_dev, count, d, gl_l2_row_stride(d),
                        rows_i8_dev, norms_dev);
     GL_LAUNCH_CHECK();

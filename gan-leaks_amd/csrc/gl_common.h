@@ -4,13 +4,31 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <vector>
 #include "../../include/ganleaks.h"
+
+struct gl_prof_span {
+    int tag;
+    hipEvent_t start, stop;
+};
 
 struct gl_ctx {
     int device;
     hipStream_t own_stream;
     hipStream_t stream;      // the stream work is enqueued on (own_stream or the caller's)
     float *zero_page;        // 4 KiB of zeros on the device: source for out-of-image taps
+    bool prof_on;            // gl_prof_enable: bracket tagged kernel launches with HIP events
+    std::vector<gl_prof_span> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+};
+
+// RAII bracket around one kernel launch; a no-op unless profiling is enabled on the context.
+struct gl_prof_scope {
+    gl_ctx *ctx;
+    gl_prof_span span;
+    bool active;
+    gl_prof_scope(gl_ctx *c, int tag);
+    ~gl_prof_scope();
 };
 
 void gl_set_error(const char *fmt, ...);

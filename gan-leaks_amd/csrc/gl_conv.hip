@@ -276,6 +276,7 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gather_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
     hipLaunchKernelGGL(gather_conv_kernel, dim3((unsigned)(m_tiles * n_tiles), phases), dim3(THREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles);
     GL_LAUNCH_CHECK();
     return GL_OK;
@@ -287,6 +288,7 @@ int gl_launch_convt_rgb_tanh(gl_ctx *ctx, const float *in, int64_t n_img, int H,
     GL_REQUIRE(Cin % 4 == 0, "convt_rgb: Cin must be a multiple of 4");
     if (n_img == 0) return GL_OK;
     const int64_t total = n_img * H * W;
+    gl_prof_scope prof_(ctx, GL_PROF_CONVT_RGB);
     hipLaunchKernelGGL(convt_rgb_tanh_kernel, dim3((unsigned)gl_ceil_div(total, THREADS)), dim3(THREADS), 0, ctx->stream, in, n_img, H, W, Cin, w,
                        bias, out_f32, out_u8);
     GL_LAUNCH_CHECK();

@@ -160,6 +160,7 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
+    gl_prof_scope prof_(ctx, GL_PROF_L2_KNN);
     hipLaunchKernelGGL(l2_knn_i8_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(THREADS), lds, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows,
                        index_base, query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
                        (int)n_tiles);

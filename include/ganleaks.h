@@ -63,6 +63,17 @@ int gl_event_destroy(void *event);
 int gl_event_record(gl_ctx *ctx, void *event);
 int gl_event_elapsed_ms(void *start, void *stop, float *out_ms);   /* synchronises on `stop` */
 
+/* per-kernel timing: while enabled, every launch of a tagged kernel is bracketed by two HIP events on
+ * the context stream.  gl_prof_read synchronises and returns the summed duration and launch count
+ * of one tag since the last gl_prof_reset. */
+#define GL_PROF_GATHER_CONV 0   /* fp32-MFMA gather convolution (generator layers 0-3) */
+#define GL_PROF_L2_KNN 1        /* int8-MFMA pairwise L2 + argmin */
+#define GL_PROF_CONVT_RGB 2     /* generator tail: ConvT -> 3 channels + tanh + quantise */
+#define GL_PROF_L2_PREPARE 3    /* u8 -> biased int8 + norms */
+int gl_prof_enable(gl_ctx *ctx, int on);
+int gl_prof_read(gl_ctx *ctx, int tag, double *out_total_ms, int64_t *out_launches);
+int gl_prof_reset(gl_ctx *ctx);
+
 /* ---------------------------------------------------------------- 8-bit image codec */
 /* float images in [-1,1] -> u8 codes, exactly when x == fl32(2*(u/255.)-1)
  * (attack_models/utils.py:82 followed by fbb.py:134 `.float()`).  *off_lattice_dev (int32, device,
