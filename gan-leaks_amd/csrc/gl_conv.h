@@ -12,7 +12,7 @@ struct GlGatherConv {
     // packed weights: [phases][cols_pad][K] fp32, K = ntaps * Cin contiguous
     const float *wpack;
     int cols;                   // real GEMM columns (output channels per position)
-    int cols_pad;               // multiple of 128
+    int cols_pad;               // multiple of 128 (wide tile) or of 64 (narrow tile)
     int ntaps;
     // per phase: taps packed 2 bits each (value+1) -> input offset (dy,dx) in {-1,0,1}
     uint32_t tap_dy[4], tap_dx[4];
@@ -29,7 +29,7 @@ struct GlGatherConv {
 
 int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 
-// ConvTranspose2d(Cin -> 3, k4 s2 p1) + bias + tanh (+ 8-bit quantisation), VALU kernel.
-// in: NHWC [n][H][W][Cin]; w: reference layout [Cin][3][4][4]; out_f32 / out_u8: NCHW [n][3][2H][2W], either may be NULL.
-int gl_launch_convt_rgb_tanh(gl_ctx *ctx, const float *in, int64_t n_img, int H, int W, int Cin, const float *w, const float *bias,
-                             float *out_f32, uint8_t *out_u8);
+// second half of the generator tail: col2im of P[pos][(ky*4+kx)*3+co] (the 48-column scatter-form GEMM
+// of ConvTranspose2d(Cin -> 3, k4 s2 p1)) + bias + tanh (+ 8-bit quantisation).
+// P: [n][H][W][48]; out_f32 / out_u8: NCHW [n][3][2H][2W], either may be NULL.
+int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t n_img, int H, int W, const float *bias, float *out_f32, uint8_t *out_u8);

@@ -23,15 +23,21 @@ namespace {
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int THREADS = 256;
-constexpr int OPER_BYTES = BM * BK * 4;   // 16 KiB
+constexpr int BK = 32;        // floats of K per slice (128 B rows in LDS)
+constexpr int THREADS = 256;  // 4 waves
 
 __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 
+// WAVES_M x WAVES_N waves (product 4), each owning TM x TN MFMA tiles of 32 x 32.
+//   <2,2,2,2>: 128 positions x 128 channels per workgroup (generator layers 0-3)
+//   <4,1,1,2>: 128 positions x  64 channels (narrow outputs: the 48-column RGB tail)
+template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherConv p, int m_tiles, int n_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16 KiB | B 16 KiB]; reused for output rows
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int A_PER = BM / 32, B_PER = BN / 32;   // 16-B chunks (= 8-row pieces) each thread / wave stages per slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A | B]; reused for output rows
 
     const int phase = blockIdx.y;
     const unsigned nwg = (unsigned)m_tiles * (unsigned)n_tiles;
@@ -43,7 +49,7 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int K = p.ntaps * p.Cin;
     const int nk = K / BK;
@@ -51,17 +57,16 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     const uint32_t tdy = p.tap_dy[phase], tdx = p.tap_dx[phase];
     const float *__restrict__ wp = p.wpack + (int64_t)phase * p.cols_pad * K;
 
-    // ---- per-thread staging bookkeeping: 4 A rows + 4 B rows, one 16-B chunk each
+    // ---- per-thread staging bookkeeping: one 16-B chunk of A_PER activation rows and B_PER weight rows
     const int rsub = lane >> 3, slot = lane & 7;
-    int64_t a_off[4];     // element offset of (img, y, x, 0)
-    int a_y[4], a_x[4];   // -1000000 marks a row beyond `positions`
-    int a_chunk[4];
-    const float *b_src[4];
+    int64_t a_off[A_PER];     // element offset of (img, y, x, 0)
+    int a_y[A_PER], a_x[A_PER];   // y = -1000000 marks a row beyond `positions`
+    int a_chunk[A_PER];
+    const float *b_src[B_PER];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + rsub;
-        const int chunk = slot ^ swz(r);
-        a_chunk[i] = chunk * 4;
+    for (int i = 0; i < A_PER; ++i) {
+        const int r = (wave * A_PER + i) * 8 + rsub;
+        a_chunk[i] = (slot ^ swz(r)) * 4;
         const int64_t pos = m0 + r;
         if (pos < p.positions) {
             const int64_t img = pos / HW;
@@ -74,7 +79,11 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
             a_x[i] = 0;
             a_off[i] = 0;
         }
-        b_src[i] = wp + (int64_t)(c0 + r) * K + chunk * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+        const int r = (wave * B_PER + i) * 8 + rsub;
+        b_src[i] = wp + (int64_t)(c0 + r) * K + (slot ^ swz(r)) * 4;
     }
 
     auto stage = [&](int kt, char *buf) {
@@ -85,21 +94,21 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
         const int dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
         const int64_t shift = ((int64_t)dy * p.W + dx) * p.Cin + ci0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < A_PER; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
             const float *src = ok ? p.in + a_off[i] + shift + a_chunk[i] : p.zero;
-            gl_glds16(src, buf + (wave * 4 + i) * 1024);
+            gl_glds16(src, buf + (wave * A_PER + i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + k0, buf + OPER_BYTES + (wave * 4 + i) * 1024);
+        for (int i = 0; i < B_PER; ++i) gl_glds16(b_src[i] + k0, buf + A_BYTES + (wave * B_PER + i) * 1024);
     };
 
-    v16f acc[2][2];
+    v16f acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -107,26 +116,30 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     const int frow = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();   // slice kt has landed (vmcnt(0)) and nobody still reads the other buffer
-        char *cur = smem + (kt & 1) * 2 * OPER_BYTES;
-        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * OPER_BYTES);
-        const char *la = cur + (wm * 64) * (BK * 4);
-        const char *lb = cur + OPER_BYTES + (wn * 64) * (BK * 4);
+        char *cur = smem + (kt & 1) * BUF_BYTES;
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF_BYTES);
+        const char *la = cur + (wm * TM * 32) * (BK * 4);
+        const char *lb = cur + A_BYTES + (wn * TN * 32) * (BK * 4);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int chunk = 2 * g + fh;
-            v4f a[2], b[2];
+            v4f a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 const int r = i * 32 + frow;
                 a[i] = *reinterpret_cast<const v4f *>(la + r * (BK * 4) + ((chunk ^ swz(r)) << 4));
-                b[i] = *reinterpret_cast<const v4f *>(lb + r * (BK * 4) + ((chunk ^ swz(r)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = j * 32 + frow;
+                b[j] = *reinterpret_cast<const v4f *>(lb + r * (BK * 4) + ((chunk ^ swz(r)) << 4));
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
     }
 
@@ -147,16 +160,16 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     __syncthreads();
     // C layout (32x32): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = c0 + wn * 64 + j * 32 + frow;
+    for (int j = 0; j < TN; ++j) {
+        const int c = c0 + (wn * TN + j) * 32 + frow;
         if (c >= p.cols) continue;
         const int cm = c % p.cmod;
         const float sc = p.scale[cm], sh = p.shift[cm];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 const int64_t o = orow[row];
                 if (o < 0) continue;
                 float v = fmaf(acc[i][j][r], sc, sh);
@@ -167,12 +180,15 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 }
 
 // ---------------------------------------------------------------------------------------------
-// ConvTranspose2d(Cin -> 3, k4, s2, p1) + bias + tanh (+ quantise).  Three output channels cannot
-// fill a matrix-core tile, so this layer runs on the vector ALUs: one thread owns the 2 x 2 output
-// pixels of one input position (all four sub-pixel phases, 12 accumulators) and walks the 3 x 3
-// input neighbourhood; the 48 weights of each input channel are wave-uniform (scalar loads).
-//   out(2y+py, 2x+px) = sum over neighbours (dy,dx) with ky = KY[dy][py], kx = KY[dx][px]
-//   KY: (dy=-1,py=0)->3  (0,0)->1  (0,1)->2  (+1,1)->0
+// Tail of the generator: ConvTranspose2d(Cin -> 3, k4, s2, p1) + bias + tanh (+ 8-bit code).
+// Three output channels cannot fill a matrix-core tile per sub-pixel phase, so the layer is split:
+//   1. scatter form on the matrix cores: P[pos][(ky*4+kx)*3+co] = sum_ci in[pos][ci] * W[ci][co][ky][kx]
+//      -- one dense GEMM [positions x Cin] x [Cin x 48] (gather_conv_kernel<4,1,1,2>, single tap);
+//   2. this kernel gathers the four contributions of every output pixel (col2im), adds the bias,
+//      applies tanh and writes NCHW fp32 and/or the 8-bit code.  HBM-bound.
+//   out(2y+py, 2x+px) = sum over (dy,ky) in T(py), (dx,kx) in T(px) of P[y+dy][x+dx][ky][kx]
+//   T(0) = {(0,1), (-1,3)},  T(1) = {(+1,0), (0,2)}      (oy = 2*iy - 1 + ky)
+// One thread per input-grid position = 2 x 2 output pixels x 3 channels.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t quantize_byte(float x)
 {
@@ -182,9 +198,9 @@ __device__ __forceinline__ uint32_t quantize_byte(float x)
     return (uint32_t)(int)t;
 }
 
-__global__ void __launch_bounds__(THREADS) convt_rgb_tanh_kernel(const float *__restrict__ in, int64_t n_img, int H, int W, int Cin,
-                                                                  const float *__restrict__ w, const float *__restrict__ bias,
-                                                                  float *__restrict__ out_f32, uint8_t *__restrict__ out_u8)
+__global__ void __launch_bounds__(THREADS) col2im_rgb_tanh_kernel(const float *__restrict__ P, int64_t n_img, int H, int W,
+                                                                   const float *__restrict__ bias, float *__restrict__ out_f32,
+                                                                   uint8_t *__restrict__ out_u8)
 {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = n_img * H * W;
@@ -192,59 +208,27 @@ __global__ void __launch_bounds__(THREADS) convt_rgb_tanh_kernel(const float *__
     const int64_t img = gid / (H * W);
     const int rem = (int)(gid - img * (H * W));
     const int y = rem / W, x = rem - y * W;
-
-    float acc[2][2][3];   // [py][px][co]
+    const int Ho = 2 * H, Wo = 2 * W;
+    constexpr int DY[2][2] = {{0, -1}, {1, 0}};
+    constexpr int KY[2][2] = {{1, 3}, {0, 2}};
+    float acc[2][2][3];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int py = 0; py < 2; ++py)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int px = 0; px < 2; ++px) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[a][b][c] = 0.0f;
-
-    const float *nb[3][3];
-    bool ok[3][3];
+            for (int co = 0; co < 3; ++co) acc[py][px][co] = 0.0f;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
+            for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int yy = y + dy, xx = x + dx;
-            ok[dy + 1][dx + 1] = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-            nb[dy + 1][dx + 1] = in + ((img * H + yy) * W + xx) * (int64_t)Cin;
-        }
-
-    for (int ci = 0; ci < Cin; ci += 4) {
-        float4 v[3][3];
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int yy = y + DY[py][ty], xx = x + DY[px][tx];
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                    const float *src = P + (gid + (int64_t)DY[py][ty] * W + DY[px][tx]) * 48 + (KY[py][ty] * 4 + KY[px][tx]) * 3;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b)
-                v[a][b] = ok[a][b] ? *reinterpret_cast<const float4 *>(nb[a][b] + ci) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float *wc = w + (int64_t)(ci + u) * 48;   // [co][ky][kx], wave-uniform
-#pragma unroll
-            for (int a = 0; a < 3; ++a)
-#pragma unroll
-                for (int b = 0; b < 3; ++b) {
-                    const float val = u == 0 ? v[a][b].x : u == 1 ? v[a][b].y : u == 2 ? v[a][b].z : v[a][b].w;
-#pragma unroll
-                    for (int py = 0; py < 2; ++py) {
-                        // dy = a-1 contributes to phase py iff (dy,py) in {(-1,0),(0,0),(0,1),(1,1)}
-                        if ((a == 0 && py == 1) || (a == 2 && py == 0)) continue;
-                        const int ky = a == 0 ? 3 : (a == 2 ? 0 : (py == 0 ? 1 : 2));
-#pragma unroll
-                        for (int px = 0; px < 2; ++px) {
-                            if ((b == 0 && px == 1) || (b == 2 && px == 0)) continue;
-                            const int kx = b == 0 ? 3 : (b == 2 ? 0 : (px == 0 ? 1 : 2));
-#pragma unroll
-                            for (int co = 0; co < 3; ++co) acc[py][px][co] = fmaf(val, wc[co * 16 + ky * 4 + kx], acc[py][px][co]);
-                        }
-                    }
+                    for (int co = 0; co < 3; ++co) acc[py][px][co] += src[co];
                 }
         }
-    }
-
-    const int Ho = 2 * H, Wo = 2 * W;
 #pragma unroll
     for (int co = 0; co < 3; ++co) {
         const float bco = bias[co];
@@ -258,39 +242,46 @@ __global__ void __launch_bounds__(THREADS) convt_rgb_tanh_kernel(const float *__
     }
 }
 
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
+{
+    constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
+    constexpr int lds = 2 * (BM + BN) * BK * 4;
+    const int64_t m_tiles = gl_ceil_div(p.positions, BM);
+    const int n_tiles = p.cols_pad / BN;
+    GL_REQUIRE(p.cols_pad % BN == 0 && p.cols <= p.cols_pad, "gather_conv: cols_pad=%d must be a multiple of %d", p.cols_pad, BN);
+    GL_REQUIRE(m_tiles * n_tiles < (1ll << 31), "gather_conv: grid too large");
+    static bool attr_set = false;
+    auto kern = gather_conv_kernel<WAVES_M, WAVES_N, TM, TN>;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles), phases), dim3(THREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 }  // namespace
 
 int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
     GL_REQUIRE(p.Cin % BK == 0, "gather_conv: Cin=%d must be a multiple of %d", p.Cin, BK);
-    GL_REQUIRE(p.cols_pad % BN == 0 && p.cols <= p.cols_pad, "gather_conv: cols_pad=%d must be a multiple of %d", p.cols_pad, BN);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv: bad phases/taps");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.wpack) & 15) == 0, "gather_conv: unaligned operand");
     if (p.positions == 0) return GL_OK;
-    const int64_t m_tiles = gl_ceil_div(p.positions, BM);
-    const int n_tiles = p.cols_pad / BN;
-    GL_REQUIRE(m_tiles * n_tiles < (1ll << 31), "gather_conv: grid too large");
-    static bool attr_set = false;
-    const int lds = 4 * OPER_BYTES;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gather_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
-    hipLaunchKernelGGL(gather_conv_kernel, dim3((unsigned)(m_tiles * n_tiles), phases), dim3(THREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
+    if (p.cols_pad % 128 == 0) return launch_gather<2, 2, 2, 2>(ctx, p, phases);
+    return launch_gather<4, 1, 1, 2>(ctx, p, phases);
 }
 
-int gl_launch_convt_rgb_tanh(gl_ctx *ctx, const float *in, int64_t n_img, int H, int W, int Cin, const float *w, const float *bias,
-                             float *out_f32, uint8_t *out_u8)
+int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t n_img, int H, int W, const float *bias, float *out_f32, uint8_t *out_u8)
 {
-    GL_REQUIRE(Cin % 4 == 0, "convt_rgb: Cin must be a multiple of 4");
     if (n_img == 0) return GL_OK;
     const int64_t total = n_img * H * W;
     gl_prof_scope prof_(ctx, GL_PROF_CONVT_RGB);
-    hipLaunchKernelGGL(convt_rgb_tanh_kernel, dim3((unsigned)gl_ceil_div(total, THREADS)), dim3(THREADS), 0, ctx->stream, in, n_img, H, W, Cin, w,
-                       bias, out_f32, out_u8);
+    hipLaunchKernelGGL(col2im_rgb_tanh_kernel, dim3((unsigned)gl_ceil_div(total, THREADS)), dim3(THREADS), 0, ctx->stream, P, n_img, H, W, bias,
+                       out_f32, out_u8);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

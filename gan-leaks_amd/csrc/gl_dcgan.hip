@@ -18,6 +18,8 @@ struct gl_dcgan {
     bool have_w[5], have_bn[4], have_bias;
     int64_t chunk, ws_chunk;   // requested / allocated images per pass
     float *ws_z, *ws_a[4];     // z padded; outputs of layers 0..3
+    float *ws_p;               // scatter-form output of layer 4: [img][H*W][16 taps * nc]
+    float *ident_scale, *ident_shift;   // epilogue constants (1, 0) for the layer-4 GEMM
 };
 
 namespace {
@@ -53,6 +55,8 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
     (void)hipFree(g->ws_z);
     g->ws_z = nullptr;
     for (int l = 0; l < 4; ++l) { (void)hipFree(g->ws_a[l]); g->ws_a[l] = nullptr; }
+    (void)hipFree(g->ws_p);
+    g->ws_p = nullptr;
     g->ws_chunk = 0;
     GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
     int hw = 16;
@@ -60,6 +64,7 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
         GL_HIP(hipMalloc((void **)&g->ws_a[l], (size_t)want * hw * g->cout[l] * 4));
         hw *= 4;
     }
+    GL_HIP(hipMalloc((void **)&g->ws_p, (size_t)want * 32 * 32 * 16 * g->nc * 4));
     g->ws_chunk = want;
     return GL_OK;
 }
@@ -88,6 +93,14 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->chunk = 0;
     g->ws_chunk = 0;
     g->ws_z = nullptr;
+    g->ws_p = nullptr;
+    g->ident_scale = g->ident_shift = nullptr;
+    {
+        std::vector<float> one(16 * channels_img, 1.0f), zero(16 * channels_img, 0.0f);
+        int rc = upload(ctx, &g->ident_scale, one);
+        if (rc == GL_OK) rc = upload(ctx, &g->ident_shift, zero);
+        if (rc != GL_OK) { delete g; return rc; }
+    }
     *out = g;
     return GL_OK;
 }
@@ -100,6 +113,9 @@ int gl_dcgan_destroy(gl_dcgan *g)
     for (int l = 0; l < 4; ++l) { (void)hipFree(g->scale[l]); (void)hipFree(g->shift[l]); (void)hipFree(g->ws_a[l]); }
     (void)hipFree(g->bias_out);
     (void)hipFree(g->ws_z);
+    (void)hipFree(g->ws_p);
+    (void)hipFree(g->ident_scale);
+    (void)hipFree(g->ident_shift);
     delete g;
     return GL_OK;
 }
@@ -140,7 +156,13 @@ int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
                         }
                     }
     } else {
-        pk.assign(w, w + (size_t)ci_n * co_n * 16);   // tail kernel reads the reference layout directly
+        // scatter form: one GEMM column per (ky, kx, co); [64][Cin], column = (ky*4+kx)*nc + co
+        const int K = ci_n, cols_pad = (int)gl_ceil_div(16 * co_n, 64) * 64;
+        pk.assign((size_t)cols_pad * K, 0.0f);
+        for (int ky = 0; ky < 4; ++ky)
+            for (int kx = 0; kx < 4; ++kx)
+                for (int co = 0; co < co_n; ++co)
+                    for (int ci = 0; ci < ci_n; ++ci) pk[((size_t)(ky * 4 + kx) * co_n + co) * K + ci] = W(ci, co, ky, kx);
     }
     int rc = upload(g->ctx, &g->wpack[layer], pk);
     if (rc != GL_OK) return rc;
@@ -236,9 +258,20 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
             if (rc != GL_OK) return rc;
             hw *= 2;
         }
-        // layer 4: ConvT k4 s2 p1 -> 3 channels, + bias, tanh, (quantise)
-        rc = gl_launch_convt_rgb_tanh(ctx, g->ws_a[3], m, hw, hw, g->cin[4], g->wpack[4], g->bias_out,
-                                      out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr, out_u8_dev ? out_u8_dev + i0 * img_elems : nullptr);
+        // layer 4: ConvT k4 s2 p1 -> 3 channels: scatter-form GEMM (48 columns) on the matrix cores,
+        // then col2im + bias + tanh (+ quantise)
+        {
+            GlGatherConv p = {};
+            p.in = g->ws_a[3]; p.positions = m * hw * hw; p.H = hw; p.W = hw; p.Cin = g->cin[4];
+            p.wpack = g->wpack[4]; p.cols = 16 * g->nc; p.cols_pad = (int)gl_ceil_div(p.cols, 64) * 64; p.ntaps = 1;
+            p.tap_dy[0] = 1; p.tap_dx[0] = 1;
+            p.out = g->ws_p; p.Ho = hw; p.Wo = hw; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0;
+            p.scale = g->ident_scale; p.shift = g->ident_shift; p.cmod = p.cols; p.act = 0; p.zero = ctx->zero_page;
+            rc = gl_launch_gather_conv(ctx, p, 1);
+            if (rc != GL_OK) return rc;
+        }
+        rc = gl_launch_col2im_rgb_tanh(ctx, g->ws_p, m, hw, hw, g->bias_out, out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr,
+                                       out_u8_dev ? out_u8_dev + i0 * img_elems : nullptr);
         if (rc != GL_OK) return rc;
     }
     return GL_OK;
