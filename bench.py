@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--bank", type=int, default=100000)
     ap.add_argument("--batch-size", type=int, default=64)
     ap.add_argument("--chunk", type=int, default=0, help="generator images per pass (0 = library default)")
-    ap.add_argument("--cpu-queries", type=int, default=8, help="queries timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(16, usable cores))")
     ap.add_argument("--check-queries", type=int, default=64, help="queries checked against the oracle after the run")
     args = ap.parse_args()

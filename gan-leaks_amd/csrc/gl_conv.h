@@ -20,6 +20,9 @@ struct GlGatherConv {
     float *out;
     int Ho, Wo, omul;
     int oy[4], ox[4];
+    // planar != 0: write column-major out[c * ld_planar + position] instead (single phase, identity position map)
+    int planar;
+    int64_t ld_planar;
     // epilogue: v = acc * scale[c % cmod] + shift[c % cmod]; act 0 none, 1 relu
     const float *scale, *shift;
     int cmod;
@@ -31,5 +34,6 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 
 // second half of the generator tail: col2im of P[pos][(ky*4+kx)*3+co] (the 48-column scatter-form GEMM
 // of ConvTranspose2d(Cin -> 3, k4 s2 p1)) + bias + tanh (+ 8-bit quantisation).
-// P: [n][H][W][48]; out_f32 / out_u8: NCHW [n][3][2H][2W], either may be NULL.
-int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t n_img, int H, int W, const float *bias, float *out_f32, uint8_t *out_u8);
+// P: column-major [48][ldp] over positions (n, y, x); out_f32 / out_u8: NCHW [n][3][2H][2W], either may be NULL.
+int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t ldp, int64_t n_img, int H, int W, const float *bias, float *out_f32,
+                              uint8_t *out_u8);

@@ -165,6 +165,24 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
         if (c >= p.cols) continue;
         const int cm = c % p.cmod;
         const float sc = p.scale[cm], sh = p.shift[cm];
+        if (p.planar) {
+            // column-major output [cols][ld_planar]: registers 4g..4g+3 are four consecutive positions -> one 16-B store
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t o = orow[(wm * TM + i) * 32 + 8 * g + 4 * fh];
+                    if (o < 0) continue;
+                    float4 v;
+                    v.x = fmaf(acc[i][j][4 * g + 0], sc, sh);
+                    v.y = fmaf(acc[i][j][4 * g + 1], sc, sh);
+                    v.z = fmaf(acc[i][j][4 * g + 2], sc, sh);
+                    v.w = fmaf(acc[i][j][4 * g + 3], sc, sh);
+                    if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4 *>(p.out + (int64_t)c * p.ld_planar + o) = v;
+                }
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -182,7 +200,7 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 // ---------------------------------------------------------------------------------------------
 // Tail of the generator: ConvTranspose2d(Cin -> 3, k4, s2, p1) + bias + tanh (+ 8-bit code).
 // Three output channels cannot fill a matrix-core tile per sub-pixel phase, so the layer is split:
-//   1. scatter form on the matrix cores: P[pos][(ky*4+kx)*3+co] = sum_ci in[pos][ci] * W[ci][co][ky][kx]
+//   1. scatter form on the matrix cores: P[(ky*4+kx)*3+co][pos] (column-major) = sum_ci in[pos][ci] * W[ci][co][ky][kx]
 //      -- one dense GEMM [positions x Cin] x [Cin x 48] (gather_conv_kernel<4,1,1,2>, single tap);
 //   2. this kernel gathers the four contributions of every output pixel (col2im), adds the bias,
 //      applies tanh and writes NCHW fp32 and/or the 8-bit code.  HBM-bound.
@@ -198,10 +216,11 @@ __device__ __forceinline__ uint32_t quantize_byte(float x)
     return (uint32_t)(int)t;
 }
 
-__global__ void __launch_bounds__(THREADS) col2im_rgb_tanh_kernel(const float *__restrict__ P, int64_t n_img, int H, int W,
+__global__ void __launch_bounds__(THREADS) col2im_rgb_tanh_kernel(const float *__restrict__ P, int64_t ldp, int64_t n_img, int H, int W,
                                                                    const float *__restrict__ bias, float *__restrict__ out_f32,
                                                                    uint8_t *__restrict__ out_u8)
 {
+    // P is column-major: P[col * ldp + position], so a wave (consecutive x) reads 256 contiguous bytes per column
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = n_img * H * W;
     if (gid >= total) return;
@@ -224,9 +243,9 @@ __global__ void __launch_bounds__(THREADS) col2im_rgb_tanh_kernel(const float *_
                 for (int tx = 0; tx < 2; ++tx) {
                     const int yy = y + DY[py][ty], xx = x + DY[px][tx];
                     if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                    const float *src = P + (gid + (int64_t)DY[py][ty] * W + DY[px][tx]) * 48 + (KY[py][ty] * 4 + KY[px][tx]) * 3;
+                    const float *src = P + (int64_t)((KY[py][ty] * 4 + KY[px][tx]) * 3) * ldp + gid + (int64_t)DY[py][ty] * W + DY[px][tx];
 #pragma unroll
-                    for (int co = 0; co < 3; ++co) acc[py][px][co] += src[co];
+                    for (int co = 0; co < 3; ++co) acc[py][px][co] += src[co * ldp];
                 }
         }
 #pragma unroll
@@ -270,18 +289,23 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
     GL_REQUIRE(p.Cin % BK == 0, "gather_conv: Cin=%d must be a multiple of %d", p.Cin, BK);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv: bad phases/taps");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.wpack) & 15) == 0, "gather_conv: unaligned operand");
+    if (p.planar)
+        GL_REQUIRE(phases == 1 && p.omul == 1 && p.Ho == p.H && p.Wo == p.W && p.positions % 4 == 0 && p.ld_planar % 4 == 0 &&
+                       p.ld_planar >= p.positions && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
+                   "gather_conv: planar output needs an identity position map and 4-aligned sizes");
     if (p.positions == 0) return GL_OK;
     if (p.cols_pad % 128 == 0) return launch_gather<2, 2, 2, 2>(ctx, p, phases);
     return launch_gather<4, 1, 1, 2>(ctx, p, phases);
 }
 
-int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t n_img, int H, int W, const float *bias, float *out_f32, uint8_t *out_u8)
+int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t ldp, int64_t n_img, int H, int W, const float *bias, float *out_f32,
+                              uint8_t *out_u8)
 {
     if (n_img == 0) return GL_OK;
     const int64_t total = n_img * H * W;
     gl_prof_scope prof_(ctx, GL_PROF_CONVT_RGB);
-    hipLaunchKernelGGL(col2im_rgb_tanh_kernel, dim3((unsigned)gl_ceil_div(total, THREADS)), dim3(THREADS), 0, ctx->stream, P, n_img, H, W, bias,
-                       out_f32, out_u8);
+    hipLaunchKernelGGL(col2im_rgb_tanh_kernel, dim3((unsigned)gl_ceil_div(total, THREADS)), dim3(THREADS), 0, ctx->stream, P, ldp, n_img, H, W,
+                       bias, out_f32, out_u8);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -78,7 +78,7 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     GL_REQUIRE(ctx && out, "gl_dcgan_create: NULL argument");
     GL_REQUIRE(z_dim > 0 && z_dim <= 4096, "gl_dcgan_create: z_dim=%d unsupported", z_dim);
     GL_REQUIRE(channels_img == 3, "gl_dcgan_create: channels_img=%d unsupported (the RGB tail kernel writes 3 channels)", channels_img);
-    GL_REQUIRE(features_g > 0 && features_g % 8 == 0, "gl_dcgan_create: features_g=%d must be a multiple of 8", features_g);
+    GL_REQUIRE(features_g > 0 && features_g % 16 == 0, "gl_dcgan_create: features_g=%d must be a multiple of 16 (K slices of 32 channels)", features_g);
     gl_dcgan *g = new gl_dcgan();
     g->ctx = ctx;
     g->z_dim = z_dim;
@@ -265,12 +265,12 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
             p.in = g->ws_a[3]; p.positions = m * hw * hw; p.H = hw; p.W = hw; p.Cin = g->cin[4];
             p.wpack = g->wpack[4]; p.cols = 16 * g->nc; p.cols_pad = (int)gl_ceil_div(p.cols, 64) * 64; p.ntaps = 1;
             p.tap_dy[0] = 1; p.tap_dx[0] = 1;
-            p.out = g->ws_p; p.Ho = hw; p.Wo = hw; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0;
+            p.out = g->ws_p; p.Ho = hw; p.Wo = hw; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0; p.planar = 1; p.ld_planar = m * hw * hw;
             p.scale = g->ident_scale; p.shift = g->ident_shift; p.cmod = p.cols; p.act = 0; p.zero = ctx->zero_page;
             rc = gl_launch_gather_conv(ctx, p, 1);
             if (rc != GL_OK) return rc;
         }
-        rc = gl_launch_col2im_rgb_tanh(ctx, g->ws_p, m, hw, hw, g->bias_out, out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr,
+        rc = gl_launch_col2im_rgb_tanh(ctx, g->ws_p, m * hw * hw, m, hw, hw, g->bias_out, out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr,
                                        out_u8_dev ? out_u8_dev + i0 * img_elems : nullptr);
         if (rc != GL_OK) return rc;
     }

@@ -95,12 +95,16 @@ def test_generator_errors(gl, synth):
 
 
 def test_small_features_g(gl, synth, oracle):
-    """features_g = 8 (the size the reference's own smoke block uses, model_torch.py:137)"""
+    """a narrow generator (features_g = 16, z_dim = 64): padded K, ragged channel tiles.
+    features_g must be a multiple of 16; the reference's own smoke block uses 8 (model_torch.py:137),
+    which is refused with a clear error."""
     from ganleaks_amd.gan_models.dcgan.model_torch import Generator
-    sd = synth.dcgan_state_dict(9, z_dim=100, features_g=8)
-    g = Generator(100, 3, 8)
+    with pytest.raises(gl.GanLeaksError):
+        Generator(100, 3, 8)._ensure()
+    sd = synth.dcgan_state_dict(9, z_dim=64, features_g=16)
+    g = Generator(64, 3, 16)
     g.load_state_dict(sd)
-    z = synth.latent(2, 5)
+    z = synth.latent(2, 5, 64)
     out = g(z)
     ref = oracle.dcgan_generator_forward(sd, z)
     assert np.abs(out - ref).max() < ATOL

@@ -1,0 +1,72 @@
+"""CPU-only: bank sharding + min-reduce of packed keys (the path's one exchange step), rehearsed
+with gloo at world_size 2 and 3.  The per-shard search is done by the oracle here (no GPU); the
+GPU test tests/test_gpu_knn.py::test_shard_invariance covers the kernel side of the same contract."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_bank, batch_size, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import ganleaks_amd
+    from ganleaks_amd import shard
+    import c_oracle
+    import oracle
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    case = ganleaks_amd.synth.attack_case(71, n_bank, 12, 12, 16)
+    q = np.concatenate([case["pos"], case["neg"]])
+    bounds = shard.shard_bounds(n_bank, batch_size, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    if hi > lo:
+        _, idx, ssd = c_oracle.knn_l2_u8(case["bank"][lo:hi], q, 1)
+        keys = oracle.pack_key(ssd, idx + lo).view(np.uint64)
+    else:
+        keys = np.full(len(q), np.iinfo(np.uint64).max >> 1, np.uint64)   # empty shard: neutral element (int64 max)
+    merged = shard.allreduce_min_keys_host(keys)
+    if rank == 0:
+        np.save(os.path.join(out_dir, "merged_%d.npy" % world), merged)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_min_reduce_equals_single_device(world, tmp_path, oracle, synth):
+    import torch.multiprocessing as mp
+    n_bank, bs = 1000, 64
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_bank, bs, str(tmp_path)), nprocs=world, join=True)
+    merged = np.load(tmp_path / ("merged_%d.npy" % world))
+    case = synth.attack_case(71, n_bank, 12, 12, 16)
+    q = np.concatenate([case["pos"], case["neg"]])
+    dist, idx, ssd = oracle.knn_l2_u8(case["bank"], q, bs)
+    s, i = oracle.unpack_key(merged.view(np.int64))
+    assert np.array_equal(i, idx) and np.array_equal(s, ssd)
+    assert i.max() < 960           # global truncation happened before the split
+
+
+def test_shard_bounds_global_truncation():
+    sys.path.insert(0, ROOT)
+    from ganleaks_amd import shard
+    assert shard.shard_bounds(100000, 64, 8) == [99968 * r // 8 for r in range(9)]
+    assert shard.shard_bounds(100000, 64, 8)[-1] == 99968
+    assert shard.shard_bounds(1000, 64, 1) == [0, 960]
+    assert shard.shard_bounds(10, 64, 4) == [0, 0, 0, 0, 0]
+    b = shard.shard_bounds(1000, 30, 7)
+    assert b[0] == 0 and b[-1] == 990 and all(b[k] <= b[k + 1] for k in range(7))
+    k = [np.array([5, 9], np.uint64), np.array([7, 2], np.uint64), np.array([6, 3], np.uint64)]
+    assert shard.merge_keys_host(k).tolist() == [5, 2]
