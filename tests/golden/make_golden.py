@@ -163,9 +163,32 @@ def make_dcgan(dc, wg):
     print("oracle vs reference generator: max abs diff", np.abs(o - outs["dcgan"]).max())
 
 
+def make_png(ref_utils):
+    """attack_models/utils.py:43-84: sorted path order + read_image (incl. the PIL resize branch)."""
+    import PIL.Image
+    d = os.path.join(HERE, "png_case")
+    os.makedirs(os.path.join(d, "sub"), exist_ok=True)
+    imgs = synth.lowpass_u8_images(99, 12, 16)
+    names = ["image_%d.png" % i for i in range(11)]
+    for i, nme in enumerate(names):
+        PIL.Image.fromarray(imgs[i].transpose(1, 2, 0)).save(os.path.join(d, nme))
+    big = synth.lowpass_u8_images(98, 1, 24)[0].transpose(1, 2, 0)      # 24x24 -> resized to 16x16 by read_image
+    PIL.Image.fromarray(big).save(os.path.join(d, "sub", "big.png"))
+    with open(os.path.join(d, "notes.txt"), "w") as f:
+        f.write("not an image\n")
+    paths = ref_utils.get_filepaths_from_dir(d, ext="png")
+    arr = np.array([ref_utils.read_image(f, 16) for f in paths])
+    np.savez(os.path.join(HERE, "png_case.npz"), rel_paths=np.array([os.path.relpath(q, d) for q in paths]), images=arr)
+    print("png_case order:", [os.path.relpath(q, d) for q in paths])
+
+
 if __name__ == "__main__":
     fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
+    if "--png-only" in sys.argv:
+        make_png(sys.modules["utils"])
+        sys.exit(0)
     make_knn(fbb)
+    make_png(sys.modules["utils"])
     ev = _refimport.load("attack_models/eval_roc.py", "ref_eval_roc")
     make_roc(ev)
     dc = _refimport.load("gan_models/dcgan/model_torch.py", "ref_dcgan_model")

@@ -1,0 +1,57 @@
+"""GPU: the fbb / eval_roc command-line drivers end to end on PNG directories (the reference's data
+format between the generate branch and the attack)."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_pngs(d, imgs_u8_nchw, prefix="image_"):
+    import PIL.Image
+    os.makedirs(d, exist_ok=True)
+    for i, im in enumerate(imgs_u8_nchw):
+        PIL.Image.fromarray(im.transpose(1, 2, 0)).save(os.path.join(d, "%s%d.png" % (prefix, i)))
+
+
+def test_fbb_main_and_eval_roc(tmp_path, monkeypatch, synth, oracle):
+    import c_oracle
+    from ganleaks_amd.attack_models import eval_roc, fbb, utils
+    case = synth.attack_case(81, 150, 25, 22, 16)
+    _write_pngs(tmp_path / "syn", case["bank"])
+    _write_pngs(tmp_path / "pos", case["pos"])
+    _write_pngs(tmp_path / "neg", case["neg"])
+    monkeypatch.chdir(tmp_path)
+    args = fbb.parse_arguments(["--exp_name", "t", "--syn_data_path", str(tmp_path / "syn"), "--pos_data_dir", str(tmp_path / "pos"),
+                                "--neg_data_dir", str(tmp_path / "neg"), "--resolution", "16", "--BATCH_SIZE", "64", "--distance", "l2"])
+    fbb.main(args)
+    out = tmp_path / "fbb_attack" / "t"
+    pos_loss = np.load(out / "pos_loss.npy")
+    neg_loss = np.load(out / "neg_loss.npy")
+    assert pos_loss.shape == (25, 1) and pos_loss.dtype == np.float64 and neg_loss.shape == (22, 1)
+    assert np.array_equal(np.load(out / "pos_idx.npy"), np.arange(25).reshape(-1, 1))
+    assert np.array_equal(np.load(out / "neg_idx.npy"), np.arange(25).reshape(-1, 1))     # the reference's len(pos_loss) quirk
+    for f in ("params.txt", "params.pkl", "0pos.png", "19pos.png", "0neg.png", "19neg.png"):
+        assert (out / f).exists(), f
+    # bank order is the sorted() path-string order (image_10 < image_2), indices refer to it
+    order = [int(os.path.basename(p)[6:-4]) for p in utils.get_filepaths_from_dir(str(tmp_path / "syn"), "png")]
+    bank_sorted = case["bank"][order]
+    pos_sorted = case["pos"][[int(os.path.basename(p)[6:-4]) for p in utils.get_filepaths_from_dir(str(tmp_path / "pos"), "png")]]
+    od, oi, _ = c_oracle.knn_l2_u8(bank_sorted, pos_sorted, 64)
+    assert np.array_equal(np.load(out / "pos_nn_idx.npy")[:, 0], oi)
+    assert np.array_equal(pos_loss[:, 0], od.astype(np.float64))
+    # eval
+    ev = eval_roc.parse_arguments(["--result_load_dir", str(out), "--attack_type", "fbb"])
+    auc, ap, prec = eval_roc.main(ev)
+    _, _, _, oauc, oap, oprec = oracle.plot_roc(-pos_loss, -neg_loss)
+    assert abs(auc - oauc) < 1e-12 and abs(ap - oap) < 1e-12 and prec == oprec
+    assert (out / "roc.png").exists()
+    # default distance is the reference's 'l2-lpips', which is announced as not built yet
+    args2 = fbb.parse_arguments(["--syn_data_path", str(tmp_path / "syn"), "--pos_data_dir", str(tmp_path / "pos"),
+                                 "--neg_data_dir", str(tmp_path / "neg"), "--resolution", "16", "--BATCH_SIZE", "64"])
+    with pytest.raises(NotImplementedError):
+        fbb.main(args2)
