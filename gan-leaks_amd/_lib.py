@@ -63,6 +63,9 @@ SIGNATURES = {
     "gl_l2_knn_i8": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gl_keys_unpack": (_i, [_p, _p, _i64, _i64, _p, _p]),
     "gl_l2_rows_u8": (_i, [_p, _p, _i64, _p, _i64, _i64, _p]),
+    "gl_l2_knn_f32": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p]),
+    "gl_keys_unpack_f32": (_i, [_p, _p, _i64, _p, _p]),
+    "gl_l2_rows_f32": (_i, [_p, _p, _i64, _p, _i64, _i64, _p]),
     "gl_fbb_knn_l2_host": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
     "gl_dcgan_create": (_i, [_p, _i, _i, _i, _pp]),
     "gl_dcgan_destroy": (_i, [_p]),

@@ -3,6 +3,11 @@
 `attack()` is the batched form of the reference's per-query `custom_knn`
 (attack_models/fbb.py:73-88): it must equal
     [custom_knn(bank, q, Loss(distance), args) for q in queries].
+
+Two arithmetic paths:
+  * images on the 8-bit lattice 2*(u/255.)-1 -- everything attack_models/utils.py:60-84 (read_image)
+    can produce -- are searched in exact integer arithmetic on the int8 matrix cores;
+  * any other fp32 images take the fixed-order fp32 path (csrc/gl_l2f32.hip).
 """
 from __future__ import annotations
 
@@ -10,7 +15,6 @@ import ctypes
 
 import numpy as np
 
-from . import _lib
 from ._lib import Context, DeviceArray, as_device, check
 
 _p = ctypes.c_void_p
@@ -20,104 +24,139 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
-def prepare_images(ctx, images):
-    """images -> DeviceArray u8 [count, D].
-
-    Accepts u8 arrays (numpy / torch / DeviceArray) of shape [count, ...] or float32 images in
-    [-1,1] that sit exactly on the 8-bit lattice 2*(u/255.)-1 -- which is everything
-    attack_models/utils.py:60-84 (read_image) can produce.  Off-lattice floats are refused: the
-    exact-integer path would silently change their values.
-    """
+def _to_device_rows(ctx, images):
+    """-> DeviceArray [count, D] of dtype uint8 or float32 (no value change)."""
     if isinstance(images, DeviceArray):
         arr = images
     else:
         if _is_torch(images):
-            kind = "f" if images.dtype.is_floating_point else "u"
             is_u8 = str(images.dtype) == "torch.uint8"
+            is_f = images.dtype.is_floating_point
         else:
             images = np.asarray(images)
-            kind = images.dtype.kind
             is_u8 = images.dtype == np.uint8
+            is_f = images.dtype.kind == "f"
         if is_u8:
             arr = as_device(ctx, images, np.uint8)
-        elif kind == "f":
+        elif is_f:
             arr = as_device(ctx, images.float() if _is_torch(images) else images.astype(np.float32, copy=False), np.float32)
         else:
             raise TypeError("images must be uint8 or float, got %r" % (images.dtype,))
+    if arr.dtype not in (np.dtype(np.uint8), np.dtype(np.float32)):
+        raise TypeError("device images must be uint8 or float32")
     count = arr.shape[0] if len(arr.shape) else 0
     d = int(np.prod(arr.shape[1:], dtype=np.int64)) if len(arr.shape) > 1 else 1
-    if arr.dtype == np.uint8:
-        return arr.view((count, d))
-    if arr.dtype != np.float32:
-        raise TypeError("device images must be uint8 or float32")
+    return arr.view((count, d))
+
+
+def encode_if_lattice(ctx, rows_f32):
+    """float32 rows -> (u8 rows, off_lattice_count).  The u8 rows are only meaningful when the count is 0."""
+    count, d = rows_f32.shape
     out = ctx.empty((count, d), np.uint8)
     flag = ctx.zeros((1,), np.int32)
-    check(ctx.lib.gl_encode_lattice_f32(ctx.handle, _p(arr.ptr), count * d, _p(out.ptr), _p(flag.ptr)))
-    bad = int(flag.numpy()[0])
+    check(ctx.lib.gl_encode_lattice_f32(ctx.handle, _p(rows_f32.ptr), count * d, _p(out.ptr), _p(flag.ptr)))
+    return out, int(flag.numpy()[0])
+
+
+def prepare_images(ctx, images):
+    """images -> u8 DeviceArray [count, D]; raises if float values are off the 8-bit lattice."""
+    rows = _to_device_rows(ctx, images)
+    if rows.dtype == np.uint8:
+        return rows
+    out, bad = encode_if_lattice(ctx, rows)
     if bad:
-        raise NotImplementedError(
-            "%d of %d pixel values are not on the 8-bit lattice 2*(u/255.)-1 that read_image produces "
-            "(attack_models/utils.py:82); the exact-integer L2 path only accepts 8-bit images" % (bad, count * d))
+        raise ValueError("%d pixel values are not on the 8-bit lattice 2*(u/255.)-1" % bad)
     return out
 
 
 class Bank:
-    """a sample bank prepared for the L2 kernel: biased int8 rows + row norms, resident in HBM.
+    """a sample bank (or query set) resident in HBM, prepared for one of the two L2 kernels.
 
+    kind 'u8' : biased int8 rows + int32 row norms (exact path)
+    kind 'f32': the fp32 rows as given (fixed-order fp32 path)
     `index_base` is the global index of row 0 (non-zero for a shard of a larger bank)."""
 
-    def __init__(self, ctx, rows_i8, norms, n, d, index_base=0, u8=None):
-        self.ctx, self.rows_i8, self.norms, self.n, self.d = ctx, rows_i8, norms, int(n), int(d)
+    def __init__(self, ctx, kind, n, d, index_base=0, rows_i8=None, norms=None, rows_f32=None, u8=None):
+        self.ctx, self.kind, self.n, self.d = ctx, kind, int(n), int(d)
         self.index_base = int(index_base)
-        self.u8 = u8
+        self.rows_i8, self.norms, self.rows_f32, self.u8 = rows_i8, norms, rows_f32, u8
 
     @classmethod
-    def from_images(cls, images, ctx=None, index_base=0, keep_u8=False):
+    def from_images(cls, images, ctx=None, index_base=0, keep_u8=False, force_kind=None):
         ctx = ctx or Context.get()
-        u8 = prepare_images(ctx, images)
-        n, d = u8.shape
+        rows = _to_device_rows(ctx, images)
+        n, d = rows.shape
+        if rows.dtype == np.float32:
+            u8, bad = (None, 1) if force_kind == "f32" else encode_if_lattice(ctx, rows)
+            if bad:
+                if force_kind == "u8":
+                    raise ValueError("%d pixel values are not on the 8-bit lattice" % bad)
+                return cls(ctx, "f32", n, d, index_base, rows_f32=rows)
+            rows = u8
+        elif force_kind == "f32":
+            f = ctx.empty((n, d), np.float32)
+            check(ctx.lib.gl_decode_u8(ctx.handle, _p(rows.ptr), n * d, _p(f.ptr)))
+            return cls(ctx, "f32", n, d, index_base, rows_f32=f)
         stride = int(ctx.lib.gl_l2_row_stride(d))
-        rows = ctx.empty((n, stride), np.int8)
+        rows_i8 = ctx.empty((n, stride), np.int8)
         norms = ctx.empty((max(n, 1),), np.int32)
-        check(ctx.lib.gl_l2_prepare(ctx.handle, _p(u8.ptr), n, d, _p(rows.ptr), _p(norms.ptr)))
+        check(ctx.lib.gl_l2_prepare(ctx.handle, _p(rows.ptr), n, d, _p(rows_i8.ptr), _p(norms.ptr)))
         ctx.sync()
-        return cls(ctx, rows, norms, n, d, index_base, u8 if keep_u8 else None)
+        return cls(ctx, "u8", n, d, index_base, rows_i8=rows_i8, norms=norms, u8=rows if keep_u8 else None)
+
+    def as_f32(self):
+        """an fp32 view of a u8 bank (needed when the other side of the comparison is off-lattice)."""
+        if self.kind == "f32":
+            return self
+        if self.u8 is None:
+            raise ValueError("bank was prepared without keep_u8; cannot convert to fp32")
+        return Bank.from_images(self.u8, self.ctx, self.index_base, force_kind="f32")
 
     def __len__(self):
         return self.n
 
 
 def knn_keys(bank, queries, n_rows=None, keys=None):
-    """launch the pairwise kernel: returns the packed keys DeviceArray [Q] (uint64):
-    (S << 32) | global index, min over bank rows [0, n_rows).  Asynchronous."""
+    """launch the pairwise kernel: packed keys DeviceArray [Q] (uint64), min over bank rows [0, n_rows).
+    u8 path: (S << 32) | global index; f32 path: (float_bits(dist) << 32) | global index.  Asynchronous."""
     ctx = bank.ctx
     if not isinstance(queries, Bank):
-        queries = Bank.from_images(queries, ctx)
+        queries = Bank.from_images(queries, ctx, keep_u8=True, force_kind="f32" if bank.kind == "f32" else None)
     if queries.d != bank.d:
         raise ValueError("query images have %d values, bank images %d" % (queries.d, bank.d))
+    if queries.kind != bank.kind:
+        # one side is off-lattice: compare in fp32 (the lattice side decodes exactly to what read_image yields)
+        bank, queries = bank.as_f32(), queries.as_f32()
     n_rows = bank.n if n_rows is None else int(n_rows)
     if keys is None:
         keys = ctx.empty((max(queries.n, 1),), np.uint64)
         check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), queries.n))
-    check(ctx.lib.gl_l2_knn_i8(ctx.handle, _p(bank.rows_i8.ptr), _p(bank.norms.ptr), n_rows, bank.index_base,
-                               _p(queries.rows_i8.ptr), _p(queries.norms.ptr), queries.n, bank.d, _p(keys.ptr)))
-    return keys, queries
+    if bank.kind == "u8":
+        check(ctx.lib.gl_l2_knn_i8(ctx.handle, _p(bank.rows_i8.ptr), _p(bank.norms.ptr), n_rows, bank.index_base,
+                                   _p(queries.rows_i8.ptr), _p(queries.norms.ptr), queries.n, bank.d, _p(keys.ptr)))
+    else:
+        check(ctx.lib.gl_l2_knn_f32(ctx.handle, _p(bank.rows_f32.ptr), n_rows, bank.index_base, _p(queries.rows_f32.ptr), queries.n, bank.d,
+                                    _p(keys.ptr)))
+    return keys, queries, bank.kind
 
 
-def unpack_keys(ctx, keys, nq, d):
+def unpack_keys(ctx, keys, nq, d, kind="u8"):
     dist = ctx.empty((max(nq, 1),), np.float32)
     idx = ctx.empty((max(nq, 1),), np.int64)
-    check(ctx.lib.gl_keys_unpack(ctx.handle, _p(keys.ptr), nq, d, _p(dist.ptr), _p(idx.ptr)))
+    if kind == "u8":
+        check(ctx.lib.gl_keys_unpack(ctx.handle, _p(keys.ptr), nq, d, _p(dist.ptr), _p(idx.ptr)))
+    else:
+        check(ctx.lib.gl_keys_unpack_f32(ctx.handle, _p(keys.ptr), nq, _p(dist.ptr), _p(idx.ptr)))
     return dist.numpy()[:nq], idx.numpy()[:nq]
 
 
 def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None):
     """nearest bank sample of every query.
 
-    queries : [Q,C,H,W] images (u8, or float on the 8-bit lattice), numpy / torch / DeviceArray / Bank
+    queries : [Q,C,H,W] images, u8 or float; numpy / torch / DeviceArray / Bank
     bank    : same, or a prepared `Bank` (then `batch_size` truncation applies to len(bank) unless the
-              bank is a shard, index_base > 0 or reduce_fn given: shards are truncated by the caller,
-              see shard.py)
+              bank is a shard -- index_base > 0 or reduce_fn given: shards are cut after the global
+              truncation, see shard.py)
     distance: 'l2' (attack_models/utils.py:161-164).  'l2-lpips' is the reference's fbb default
               (attack_models/fbb.py:148) and lands with the LPIPS kernels.
     returns (dist float32 [Q], idx int64 [Q]); idx < (N // batch_size) * batch_size (fbb.py:77),
@@ -140,11 +179,11 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
                 bank = bank.view((n_rows,) + tuple(bank.shape[1:]))
             else:
                 bank = bank[:n_rows]
-            bank = Bank.from_images(bank, ctx)
+            bank = Bank.from_images(bank, ctx, keep_u8=True)
     if n_rows == 0 and reduce_fn is None:
         # the reference dies in torch.cat([]) (fbb.py:83) with ValueError
         raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
-    keys, q = knn_keys(bank, queries, n_rows)
+    keys, q, kind = knn_keys(bank, queries, n_rows)
     if reduce_fn is not None:
         keys = reduce_fn(keys)
-    return unpack_keys(ctx, keys, q.n, bank.d)
+    return unpack_keys(ctx, keys, q.n, bank.d, kind)

@@ -73,7 +73,7 @@ def _cached_bank(syn_imgs, n_rows):
         syn_imgs.ctypes.data if isinstance(syn_imgs, np.ndarray) else id(syn_imgs))
     key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows)
     if _bank_cache["key"] != key:
-        _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows])
+        _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows], keep_u8=True)
         _bank_cache["key"] = key
     return _bank_cache["bank"]
 

@@ -12,7 +12,6 @@ import numpy as np
 
 from .. import _lib
 from .._lib import Context, check
-from ..attack import prepare_images
 
 _p = ctypes.c_void_p
 
@@ -71,7 +70,8 @@ class Loss:
     x_hat [B,C,H,W], x_gt [1,C,H,W] (broadcast) or [B,C,H,W].  Sets .loss_lpips, .loss_l2, .vec_loss like
     the reference.  Inputs may be numpy, torch (CPU / ROCm) or DeviceArray; the result is a numpy
     float32 vector, or a torch tensor on the input's device when x_hat is a torch tensor.
-    'l2' is exact-integer on the 8-bit lattice; unlike the reference it does not
+    'l2' is exact-integer for images on the 8-bit lattice and fixed-order fp32 otherwise (DESIGN.md 2);
+    unlike the reference it does not
     build an LPIPS model it never uses (utils.py:157)."""
 
     def __init__(self, distance, if_norm_reg=False, ctx=None):
@@ -93,14 +93,20 @@ class Loss:
         return self._ctx
 
     def forward(self, x_hat, x_gt):
+        from ..attack import Bank
         ctx = self.ctx
-        a = prepare_images(ctx, x_hat)
-        g = prepare_images(ctx, x_gt)
-        if a.shape[1] != g.shape[1]:
+        a = Bank.from_images(x_hat, ctx, keep_u8=True)
+        g = Bank.from_images(x_gt, ctx, keep_u8=True, force_kind="f32" if a.kind == "f32" else None)
+        if a.d != g.d:
             raise ValueError("image sizes differ")
-        out = ctx.empty((max(a.shape[0], 1),), np.float32)
-        check(ctx.lib.gl_l2_rows_u8(ctx.handle, _p(a.ptr), a.shape[0], _p(g.ptr), g.shape[0], a.shape[1], _p(out.ptr)))
-        l2 = out.numpy()[:a.shape[0]]
+        if a.kind != g.kind:
+            a, g = a.as_f32(), g.as_f32()
+        out = ctx.empty((max(a.n, 1),), np.float32)
+        if a.kind == "u8":
+            check(ctx.lib.gl_l2_rows_u8(ctx.handle, _p(a.u8.ptr), a.n, _p(g.u8.ptr), g.n, a.d, _p(out.ptr)))
+        else:
+            check(ctx.lib.gl_l2_rows_f32(ctx.handle, _p(a.rows_f32.ptr), a.n, _p(g.rows_f32.ptr), g.n, a.d, _p(out.ptr)))
+        l2 = out.numpy()[:a.n]
         if type(x_hat).__module__.startswith("torch"):
             import torch
             l2 = torch.from_numpy(l2).to(x_hat.device)

@@ -9,7 +9,7 @@ struct GlGatherConv {
     const float *in;
     int64_t positions;          // n_img * H * W   (GEMM M: one row per base-grid position)
     int H, W, Cin;
-    // packed weights: [phases][cols_pad][K] fp32, K = ntaps * Cin contiguous
+    // packed weights: [phases][cols_pad][K] fp32, K = ntaps * Cin contiguous, ordered by gl_conv_k_index
     const float *wpack;
     int cols;                   // real GEMM columns (output channels per position)
     int cols_pad;               // multiple of 128 (wide tile) or of 64 (narrow tile)
@@ -29,6 +29,9 @@ struct GlGatherConv {
     int act;
     const float *zero;          // >= 16 B of zeros (source of out-of-image taps)
 };
+
+// position of (tap, ci) inside a packed weight row: channel chunks of 32 outermost, taps inside a chunk
+static inline int64_t gl_conv_k_index(int tap, int ci, int ntaps) { return ((int64_t)(ci / 32) * ntaps + tap) * 32 + (ci % 32); }
 
 int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 

@@ -1,7 +1,7 @@
 // fp32 matrix-core convolution kernels of the generator stack
 // (gan_models/dcgan/model_torch.py:78-86 == gan_models/wgangp/model.py:40-48).
 //
-// gather_conv_kernel: C[position][channel] = sum_{tap,ci} in[pos + tap][ci] * W[channel][tap*Cin+ci]
+// gather_conv_kernel: C[position][channel] = sum_{tap,ci} in[pos + tap][ci] * W[channel][k(tap,ci)]  (k: gl_conv.h)
 //   - v_mfma_f32_32x32x2_f32: exact fp32 products and fp32 accumulation, i.e. the same arithmetic
 //     class as the reference's fp32 convolution (only the summation order differs).
 //   - workgroup tile 128 positions x 128 channels, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles
@@ -32,18 +32,21 @@ __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 //   <2,2,2,2>: 128 positions x 128 channels per workgroup (generator layers 0-3)
 //   <4,1,1,2>: 128 positions x  64 channels (narrow outputs: the 48-column RGB tail)
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherConv p, int m_tiles, int n_tiles)
+__global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int A_PER = BM / 32, B_PER = BN / 32;   // 16-B chunks (= 8-row pieces) each thread / wave stages per slice
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A | B]; reused for output rows
 
-    const int phase = blockIdx.y;
-    const unsigned nwg = (unsigned)m_tiles * (unsigned)n_tiles;
-    const unsigned id = gl_xcd_remap(blockIdx.x, nwg);
-    const int nt = (int)(id % (unsigned)n_tiles);   // neighbours share the activation panel
-    const int mt = (int)(id / (unsigned)n_tiles);
+    // logical block order: (phase, channel tile) fastest, position tile slowest -> the blocks that read the same
+    // activation panel (all phases x channel tiles of one position tile) are adjacent and, after the XCD remap,
+    // run together on one XCD: the panel is fetched into that L2 once.
+    const unsigned inner = (unsigned)phases * (unsigned)n_tiles;
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)m_tiles * inner);
+    const int mt = (int)(id / inner);
+    const int phase = (int)((id % inner) / (unsigned)n_tiles);
+    const int nt = (int)(id % (unsigned)n_tiles);
     const int64_t m0 = (int64_t)mt * BM;
     const int c0 = nt * BN;
 
@@ -87,9 +90,11 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     }
 
     auto stage = [&](int kt, char *buf) {
+        // K order: taps innermost -- slice kt = (channel chunk kt / ntaps, tap kt % ntaps) -- so consecutive slices
+        // re-read the same pixels shifted by one tap while they are still in L2
         const int k0 = kt * BK;
-        const int tap = k0 / p.Cin;
-        const int ci0 = k0 - tap * p.Cin;
+        const int tap = kt % p.ntaps;
+        const int ci0 = (kt / p.ntaps) * BK;
         const int dy = (int)((tdy >> (2 * tap)) & 3u) - 1;
         const int dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
         const int64_t shift = ((int64_t)dy * p.W + dx) * p.Cin + ci0;
@@ -269,7 +274,7 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
     const int64_t m_tiles = gl_ceil_div(p.positions, BM);
     const int n_tiles = p.cols_pad / BN;
     GL_REQUIRE(p.cols_pad % BN == 0 && p.cols <= p.cols_pad, "gather_conv: cols_pad=%d must be a multiple of %d", p.cols_pad, BN);
-    GL_REQUIRE(m_tiles * n_tiles < (1ll << 31), "gather_conv: grid too large");
+    GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv: grid too large");
     static bool attr_set = false;
     auto kern = gather_conv_kernel<WAVES_M, WAVES_N, TM, TN>;
     if (!attr_set) {
@@ -277,7 +282,7 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
         attr_set = true;
     }
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles), phases), dim3(THREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(THREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles, phases);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

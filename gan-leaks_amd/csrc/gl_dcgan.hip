@@ -151,8 +151,8 @@ int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
                     for (int tx = 0; tx < 2; ++tx) {
                         const int ky = kKy[py][ty], kx = kKy[px][tx], tap = ty * 2 + tx, phase = py * 2 + px;
                         for (int co = 0; co < co_n; ++co) {
-                            float *dst = &pk[((size_t)phase * cols_pad + co) * K + (size_t)tap * ci_n];
-                            for (int ci = 0; ci < ci_n; ++ci) dst[ci] = W(ci, co, ky, kx);
+                            float *dst = &pk[((size_t)phase * cols_pad + co) * K];
+                            for (int ci = 0; ci < ci_n; ++ci) dst[gl_conv_k_index(tap, ci, 4)] = W(ci, co, ky, kx);
                         }
                     }
     } else {

@@ -109,6 +109,16 @@ int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d,
  * when it holds one image, fbb.py:79).  u8 rows on the device. */
 int gl_l2_rows_u8(gl_ctx *ctx, const uint8_t *x_hat_u8_dev, int64_t b, const uint8_t *x_gt_u8_dev, int64_t b_gt, int64_t d, float *out_dev);
 
+/* ---- arbitrary fp32 images (values off the 8-bit lattice): fixed-order fp32 evaluation of
+ * mean((y - x)**2) (attack_models/utils.py:163): four interleaved fmaf chains over k, summed pairwise, divided by
+ * d (exact definition in gan-leaks_amd/csrc/gl_l2f32.hip, shared bit for bit with the oracle).
+ * keys[q] = min(keys[q], (float_bits(dist) << 32) | (index_base + n)); rows are [count][d] fp32, 16-byte aligned. */
+int gl_l2_knn_f32(gl_ctx *ctx, const float *bank_dev, int64_t n_rows, int64_t index_base, const float *query_dev, int64_t nq, int64_t d,
+                  uint64_t *keys_dev);
+int gl_keys_unpack_f32(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, float *dist_dev, int64_t *idx_dev);
+/* Loss('l2').forward for fp32 inputs: out[i] = dist(x_hat[i], x_gt[b_gt == 1 ? 0 : i]) */
+int gl_l2_rows_f32(gl_ctx *ctx, const float *x_hat_dev, int64_t b, const float *x_gt_dev, int64_t b_gt, int64_t d, float *out_dev);
+
 /* One-call form for host callers: u8 images in HOST memory, results in HOST memory; applies the
  * truncation n_eff = (n_bank / batch_size) * batch_size itself.  Equals
  * [custom_knn(bank, q, Loss('l2'), args) for q in queries]  (attack_models/fbb.py:73-88,156-159).

@@ -64,3 +64,28 @@ def row_norms_u8(x_u8):
     out = np.empty(len(x), np.int32)
     lib().gl_oracle_row_norms_u8(_ptr(x), len(x), d, _ptr(out))
     return out
+
+
+def knn_l2_f32(bank_f32, queries_f32, batch_size):
+    """general fp32 images: the fixed-order fp32 chain shared with the device path (fbb_oracle.c)."""
+    bank = np.ascontiguousarray(bank_f32, np.float32)
+    qs = np.ascontiguousarray(queries_f32, np.float32)
+    n_eff = (len(bank) // batch_size) * batch_size
+    if n_eff == 0:
+        raise ValueError("bank smaller than BATCH_SIZE (fbb.py:77-83)")
+    d = int(np.prod(bank.shape[1:]))
+    idx = np.empty(len(qs), np.int64)
+    dist = np.empty(len(qs), np.float32)
+    fn = lib().gl_oracle_knn_l2_f32
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    assert fn(_ptr(bank), n_eff, _ptr(qs), len(qs), d, _ptr(idx), _ptr(dist)) == 0
+    return dist, idx
+
+
+def l2_pair_f32(y, x):
+    y = np.ascontiguousarray(y, np.float32).reshape(-1)
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    fn = lib().gl_oracle_l2_pair_f32
+    fn.restype = ctypes.c_float
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    return np.float32(fn(_ptr(y), _ptr(x), y.size))

@@ -79,3 +79,50 @@ int gl_oracle_row_norms_u8(const uint8_t *x, int64_t n, int64_t d, int32_t *out)
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * General fp32 images (not on the 8-bit lattice).  attack_models/utils.py:163 computes
+ * mean((y - x)**2) in fp32 with a reduction order that depends on the torch build; this oracle and
+ * the device path (gan-leaks_amd/csrc/gl_l2f32.hip) fix one order and share it bit for bit:
+ *   d_k = fl32(y_k - x_k);  c_j = fmaf chain over k = j, j+4, ... (j = 0..3);
+ *   dist = fl32(fl32(fl32(c0 + c1) + fl32(c2 + c3)) / D)
+ * argmin over fl32 dist, first index on ties (fbb.py:86).  Within ~1e-6 of any other fp32 order.
+ * ------------------------------------------------------------------------------------------------ */
+#include <math.h>
+
+#if defined(__x86_64__)
+#define CLONES_FMA __attribute__((target_clones("default", "arch=haswell", "arch=skylake-avx512")))
+#else
+#define CLONES_FMA
+#endif
+
+CLONES_FMA
+float gl_oracle_l2_pair_f32(const float *y, const float *x, int64_t d)
+{
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t k = 0; k < d; ++k) {
+        const float t = y[k] - x[k];
+        c[k & 3] = fmaf(t, t, c[k & 3]);
+    }
+    const float s01 = c[0] + c[1], s23 = c[2] + c[3];
+    const float s = s01 + s23;
+    return s / (float)d;
+}
+
+int gl_oracle_knn_l2_f32(const float *bank, int64_t n_eff, const float *queries, int64_t nq, int64_t d, int64_t *out_idx, float *out_dist)
+{
+    if (n_eff <= 0 || d <= 0) return -1;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t q = 0; q < nq; ++q) {
+        const float *qa = queries + q * d;
+        float best = INFINITY;
+        int64_t besti = 0;
+        for (int64_t n = 0; n < n_eff; ++n) {
+            const float s = gl_oracle_l2_pair_f32(qa, bank + n * d, d);
+            if (s < best) { best = s; besti = n; }
+        }
+        out_idx[q] = besti;
+        out_dist[q] = best;
+    }
+    return 0;
+}

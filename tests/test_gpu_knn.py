@@ -58,11 +58,13 @@ def test_float_lattice_inputs_and_custom_knn(gl, synth, oracle, golden_dir):
     import torch
     d, i = custom_knn(torch.from_numpy(bank_f), torch.from_numpy(q_f[7]), loss, args)
     assert i == int(g["pos_idx"][7])
-    # off-lattice floats are refused, not silently rounded
+    # off-lattice floats are never rounded to the lattice: they take the fixed-order fp32 path
+    import c_oracle
     bad = bank_f.copy()
     bad[3, 0, 0, 0] += 1e-3
-    with pytest.raises(NotImplementedError):
-        gl.attack(q_f[:2], bad, batch_size=64)
+    d, i = gl.attack(q_f[:5], bad, batch_size=64)
+    od, oi = c_oracle.knn_l2_f32(bad, q_f[:5], 64)
+    assert np.array_equal(i, oi) and np.array_equal(d, od)
 
 
 def test_loss_forward_vector(gl, synth, oracle):
@@ -145,9 +147,45 @@ def test_shard_invariance(gl, synth, coracle):
         keys = None
         for r in reversed(range(world)):      # order must not matter
             shard = Bank.from_images(case["bank"][bounds[r]:bounds[r + 1]], ctx, index_base=bounds[r])
-            keys, _ = knn_keys(shard, qb, keys=keys)
+            keys, _, _ = knn_keys(shard, qb, keys=keys)
         d, i = unpack_keys(ctx, keys, qb.n, qb.d)
         assert np.array_equal(i, ref_i) and np.array_equal(d, ref_d)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 16), (3, 10, 10), (1071,), (5,)])
+def test_float_path_vs_oracle(shape, gl, coracle):
+    """arbitrary fp32 images: device result equals the oracle's fixed-order fp32 chain bit for bit"""
+    from ganleaks_amd.attack_models.utils import Loss
+    rng = np.random.default_rng(len(shape) + shape[0])
+    bank = rng.uniform(-1, 1, size=(333,) + shape).astype(np.float32)
+    q = rng.uniform(-1, 1, size=(70,) + shape).astype(np.float32)
+    q[3] = bank[17]
+    bank[200] = bank[40]
+    q[4] = bank[200]
+    for bs in (64, 30):
+        d, i = gl.attack(q, bank, batch_size=bs)
+        od, oi = coracle.knn_l2_f32(bank, q, bs)
+        assert np.array_equal(i, oi) and np.array_equal(d, od)
+        assert i[3] == 17 and d[3] == 0 and i[4] == 40
+    v = Loss("l2")(bank[:64], q[:1])
+    ref = np.array([coracle.l2_pair_f32(q[0], bank[k]) for k in range(64)], np.float32)
+    assert np.array_equal(v, ref)
+    # mixed: u8 bank, off-lattice float queries
+    ub = rng.integers(0, 256, size=(128,) + shape, dtype=np.uint8)
+    d, i = gl.attack(q[:9], ub, batch_size=64)
+    fb = (2.0 * (ub / 255.0) - 1.0).astype(np.float32)
+    od, oi = coracle.knn_l2_f32(fb, q[:9], 64)
+    assert np.array_equal(i, oi) and np.array_equal(d, od)
+    # shards of a float bank merge exactly like the integer path
+    from ganleaks_amd.attack import Bank, knn_keys, unpack_keys
+    ctx = gl.Context.get()
+    keys = None
+    qb = Bank.from_images(q, ctx, force_kind="f32")
+    for lo, hi in ((192, 320), (0, 100), (100, 192)):
+        keys, _, kind = knn_keys(Bank.from_images(bank[lo:hi], ctx, index_base=lo, force_kind="f32"), qb, keys=keys)
+    d, i = unpack_keys(ctx, keys, qb.n, qb.d, kind)
+    od, oi = coracle.knn_l2_f32(bank, q, 64)
+    assert np.array_equal(i, oi) and np.array_equal(d, od)
 
 
 def test_medium_vs_c_oracle(gl, synth, coracle):
