@@ -17,6 +17,8 @@
 //   - epilogue fuses BatchNorm(eval) as scale/shift and ReLU, and scatters each sub-pixel phase to
 //     its interleaved output position, NHWC.
 #include "gl_conv.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -148,58 +150,73 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
         }
     }
 
-    // ---- epilogue.  Output row index of every tile position, computed once into LDS.
+    // ---- epilogue.  Output row index of every tile position, computed once into LDS, then pulled into registers
+    // BEFORE the first store: with stores in flight hipcc drains vmcnt(0) ahead of every LDS read (it cannot tell
+    // them from pending LDS-DMA), which would serialise the whole store tail.
     __syncthreads();
-    int64_t *orow = reinterpret_cast<int64_t *>(smem);
+    int *orow = reinterpret_cast<int *>(smem);
     if (tid < BM) {
         const int64_t pos = m0 + tid;
-        int64_t o = -1;
+        int o = -1;
         if (pos < p.positions) {
             const int64_t img = pos / HW;
             const int rem = (int)(pos - img * HW);
             const int y = rem / p.W, x = rem - y * p.W;
-            o = (img * p.Ho + (y * p.omul + p.oy[phase])) * p.Wo + (x * p.omul + p.ox[phase]);
+            o = (int)((img * p.Ho + (y * p.omul + p.oy[phase])) * p.Wo + (x * p.omul + p.ox[phase]));
         }
         orow[tid] = o;
     }
     __syncthreads();
     // C layout (32x32): column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    int o32[TM][16];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int c = c0 + (wn * TN + j) * 32 + frow;
-        if (c >= p.cols) continue;
-        const int cm = c % p.cmod;
-        const float sc = p.scale[cm], sh = p.shift[cm];
-        if (p.planar) {
-            // column-major output [cols][ld_planar]: registers 4g..4g+3 are four consecutive positions -> one 16-B store
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int64_t o = orow[(wm * TM + i) * 32 + 8 * g + 4 * fh];
-                    if (o < 0) continue;
-                    float4 v;
-                    v.x = fmaf(acc[i][j][4 * g + 0], sc, sh);
-                    v.y = fmaf(acc[i][j][4 * g + 1], sc, sh);
-                    v.z = fmaf(acc[i][j][4 * g + 2], sc, sh);
-                    v.w = fmaf(acc[i][j][4 * g + 3], sc, sh);
-                    if (p.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *reinterpret_cast<float4 *>(p.out + (int64_t)c * p.ld_planar + o) = v;
-                }
-            continue;
+        for (int g = 0; g < 4; ++g) {
+            const int4 v = *reinterpret_cast<const int4 *>(&orow[(wm * TM + i) * 32 + 8 * g + 4 * fh]);
+            o32[i][4 * g + 0] = v.x; o32[i][4 * g + 1] = v.y; o32[i][4 * g + 2] = v.z; o32[i][4 * g + 3] = v.w;
         }
+    // branch-free store tail for full tiles (per-store branches make hipcc wait vmcnt(0) between stores);
+    // only the last, ragged position tile takes the checked variant.
+    const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
+    auto store_tile = [&](auto checked) {
+        constexpr bool CHECK = decltype(checked)::value;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            const int c = c0 + (wn * TN + j) * 32 + frow;
+            const bool c_ok = c < p.cols;
+            const int cm = (c_ok ? c : 0) % p.cmod;
+            const float sc = p.scale[cm], sh = p.shift[cm];
+            if (p.planar) {
+                // column-major output [cols][ld_planar]: registers 4g..4g+3 are four consecutive positions -> one 16-B store
+                float *colp = p.out + (int64_t)c * p.ld_planar;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const int64_t o = orow[row];
-                if (o < 0) continue;
-                float v = fmaf(acc[i][j][r], sc, sh);
-                if (p.act == 1) v = fmaxf(v, 0.0f);
-                p.out[o * p.cols + c] = v;
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int o = o32[i][4 * g];
+                        float4 v;
+                        v.x = fmaxf(fmaf(acc[i][j][4 * g + 0], sc, sh), relu_floor);
+                        v.y = fmaxf(fmaf(acc[i][j][4 * g + 1], sc, sh), relu_floor);
+                        v.z = fmaxf(fmaf(acc[i][j][4 * g + 2], sc, sh), relu_floor);
+                        v.w = fmaxf(fmaf(acc[i][j][4 * g + 3], sc, sh), relu_floor);
+                        if (c_ok && (!CHECK || o >= 0)) *reinterpret_cast<float4 *>(colp + o) = v;
+                    }
+            } else {
+                float *colp = p.out + c;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = o32[i][r];
+                        const float v = fmaxf(fmaf(acc[i][j][r], sc, sh), relu_floor);
+                        if (c_ok && (!CHECK || o >= 0)) colp[(int64_t)o * p.cols] = v;
+                    }
             }
-    }
+        }
+    };
+    if (m0 + BM <= p.positions) store_tile(std::false_type{});
+    else store_tile(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,13 +293,15 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
     GL_REQUIRE(p.cols_pad % BN == 0 && p.cols <= p.cols_pad, "gather_conv: cols_pad=%d must be a multiple of %d", p.cols_pad, BN);
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv: grid too large");
     static bool attr_set = false;
+    static const int lds_pad = getenv("GL_CONV_LDS") ? atoi(getenv("GL_CONV_LDS")) : 0;   // occupancy experiment knob
+    const int lds_req = lds_pad > lds ? lds_pad : lds;
     auto kern = gather_conv_kernel<WAVES_M, WAVES_N, TM, TN>;
     if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_req));
         attr_set = true;
     }
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(THREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles, phases);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(THREADS), lds_req, ctx->stream, p, (int)m_tiles, n_tiles, phases);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -294,6 +313,7 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
     GL_REQUIRE(p.Cin % BK == 0, "gather_conv: Cin=%d must be a multiple of %d", p.Cin, BK);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv: bad phases/taps");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.wpack) & 15) == 0, "gather_conv: unaligned operand");
+    GL_REQUIRE((p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv: more than 2^31 output positions in one launch");
     if (p.planar)
         GL_REQUIRE(phases == 1 && p.omul == 1 && p.Ho == p.H && p.Wo == p.W && p.positions % 4 == 0 && p.ld_planar % 4 == 0 &&
                        p.ld_planar >= p.positions && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,
