@@ -73,3 +73,27 @@ def dcgan_state_dict(seed=1234, z_dim=100, channels_img=3, features_g=64, prefix
 def latent(seed, n, z_dim=100):
     """z ~ N(0,1), float32 [n, z_dim, 1, 1] (dcgan/train_torch.py:153)."""
     return np.random.default_rng(seed).standard_normal((n, z_dim)).astype(np.float32).reshape(n, z_dim, 1, 1)
+
+
+VGG16_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]   # features[0:30]
+VGG16_CONV_KEYS = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]     # torchvision vgg16().features indices of the convs
+LPIPS_CHANNELS = [64, 128, 256, 512, 512]                               # taps relu1_2, 2_2, 3_3, 4_3, 5_3
+
+
+def vgg16_state_dict(seed=7, bias_std=0.05):
+    """Random VGG16 conv weights under torchvision's `vgg16().features` key names ({idx}.weight
+    [Cout,Cin,3,3], {idx}.bias).  The ImageNet weights the reference downloads
+    (attack_models/lpips_pytorch/models/pretrained_networks.py:99) are not available offline
+    (SURVEY.md D10); Kaiming-normal weights keep activations O(1) through the 13 layers."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    cin = 3
+    it = iter(VGG16_CONV_KEYS)
+    for v in VGG16_CFG:
+        if v == "M":
+            continue
+        k = next(it)
+        sd[f"{k}.weight"] = rng.normal(0.0, np.sqrt(2.0 / (cin * 9)), size=(v, cin, 3, 3)).astype(np.float32)
+        sd[f"{k}.bias"] = rng.normal(0.0, bias_std, size=v).astype(np.float32)
+        cin = v
+    return sd

@@ -163,6 +163,72 @@ def make_dcgan(dc, wg):
     print("oracle vs reference generator: max abs diff", np.abs(o - outs["dcgan"]).max())
 
 
+def _vgg16_features_standin(sd_np):
+    """torch.nn restatement of torchvision.models.vgg16().features[0:30] (cfg 'D'; torchvision is not
+    installed).  Only the ARCHITECTURE is restated; the reference's own vgg16 wrapper slices it
+    (pretrained_networks.py:96-134)."""
+    import torch.nn as nn
+    layers, cin = [], 3
+    for v in synth.VGG16_CFG + ["M"]:
+        if v == "M":
+            layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+        else:
+            layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+            cin = v
+    feats = nn.Sequential(*layers)
+    feats.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    return feats
+
+
+def make_lpips(fbb):
+    """attack_models/lpips_pytorch/models/networks_basic.py:134-181 PNetLin.forward (+ :222-230 NetLinLayer,
+    util/util.py:70-73 normalize_tensor, pretrained_networks.py:96-134 vgg16 slices) with the vendored lin
+    weights (pretrained_models/v0.1/vgg.pth) and a seeded random backbone; and custom_knn driven with
+    the 'l2-lpips' formula of attack_models/utils.py:166-176."""
+    sd_np = synth.vgg16_state_dict(7)
+    tv_models = sys.modules["torchvision.models"]
+
+    class _VGG(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.features = _vgg16_features_standin(sd_np)
+    tv_models.vgg16 = lambda pretrained=False: _VGG()
+    nb = sys.modules["lpips_pytorch.models.networks_basic"] if "lpips_pytorch.models.networks_basic" in sys.modules else None
+    if nb is None:
+        import lpips_pytorch.models.networks_basic as nb
+    net = nb.PNetLin(pnet_type="vgg", pnet_rand=True, pnet_tune=False, use_dropout=True, use_gpu=False, spatial=False, version="0.1")
+    lin_path = os.path.join(_refimport.REF, "attack_models/lpips_pytorch/pretrained_models/v0.1/vgg.pth")
+    lin_sd = torch.load(lin_path, map_location="cpu", weights_only=True)
+    print("lin load:", net.load_state_dict(lin_sd, strict=False))
+    net.eval()                                              # dist_model.py:100
+    np.savez(os.path.join(HERE, "lpips_lin_v0.1.npz"), **{"lin%d" % i: lin_sd["lin%d.model.1.weight" % i].numpy().reshape(-1) for i in range(5)})
+
+    def lpips_fn(x_hat, x_gt):                              # utils.py:168 -> PerceptualLoss.forward(pred=x, target=y) -> net(in0=target, in1=pred)
+        return net.forward(x_gt, x_hat).view(-1)
+
+    def loss(x_hat, x_gt):                                  # utils.py:171-177
+        return 0.2 * lpips_fn(x_hat, x_gt) + torch.mean((x_gt - x_hat) ** 2, dim=[1, 2, 3])
+
+    for name, (seed, nbank, npos, nneg, res, bs) in {"lpips_res32": (31, 40, 4, 4, 32, 16), "lpips_res64": (32, 24, 3, 3, 64, 8)}.items():
+        case = synth.attack_case(seed, nbank, npos, nneg, res, sigma=20.0)
+        bank = to_ref_tensor(case["bank"])
+        q = to_ref_tensor(np.concatenate([case["pos"], case["neg"]]))
+        with torch.no_grad():
+            lp = torch.stack([lpips_fn(bank, q[k:k + 1]) for k in range(len(q))]).numpy()        # [Q, N] pure LPIPS
+            taps = net.net[0].forward((q[:1] - net.shift) / net.scale)
+            tap_shapes = np.array([list(t.shape[1:]) for t in taps])
+            tap_sums = np.array([float(t.double().sum()) for t in taps])
+        args = types.SimpleNamespace(BATCH_SIZE=bs)
+        d, i = [], []
+        for sample in q:
+            dd, ii = fbb.custom_knn(bank, sample, loss, args)   # autograd on, as in the reference
+            d.append(dd)
+            i.append(ii)
+        np.savez(os.path.join(HERE, name + ".npz"), seed=seed, n_bank=nbank, n_pos=npos, n_neg=nneg, res=res, batch_size=bs,
+                 vgg_seed=7, lpips=lp, dist=np.array(d, np.float64), idx=np.array(i, np.int64), tap_shapes=tap_shapes, tap_sums=tap_sums)
+        print(name, "idx", i, "dist", np.round(d, 4), "lpips range", lp.min(), lp.max())
+
+
 def make_png(ref_utils):
     """attack_models/utils.py:43-84: sorted path order + read_image (incl. the PIL resize branch)."""
     import PIL.Image
@@ -184,11 +250,15 @@ def make_png(ref_utils):
 
 if __name__ == "__main__":
     fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
+    if "--lpips-only" in sys.argv:
+        make_lpips(fbb)
+        sys.exit(0)
     if "--png-only" in sys.argv:
         make_png(sys.modules["utils"])
         sys.exit(0)
     make_knn(fbb)
     make_png(sys.modules["utils"])
+    make_lpips(fbb)
     ev = _refimport.load("attack_models/eval_roc.py", "ref_eval_roc")
     make_roc(ev)
     dc = _refimport.load("gan_models/dcgan/model_torch.py", "ref_dcgan_model")

@@ -1,0 +1,30 @@
+"""Pin the LPIPS oracle against vectors produced by the reference's PNetLin (CPU only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+@pytest.mark.parametrize("name", ["lpips_res32", "lpips_res64"])
+def test_lpips_oracle_matches_reference(name, synth, oracle, golden_dir):
+    import lpips_oracle
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    lin = np.load(os.path.join(golden_dir, "lpips_lin_v0.1.npz"))
+    lin = [lin["lin%d" % i] for i in range(5)]
+    assert [len(w) for w in lin] == synth.LPIPS_CHANNELS and all((w >= 0).all() for w in lin)
+    sd = synth.vgg16_state_dict(int(g["vgg_seed"]))
+    case = synth.attack_case(int(g["seed"]), int(g["n_bank"]), int(g["n_pos"]), int(g["n_neg"]), int(g["res"]), sigma=20.0)
+    bank = oracle.dequantize_u8(case["bank"])
+    q = oracle.dequantize_u8(np.concatenate([case["pos"], case["neg"]]))
+    taps = lpips_oracle.vgg16_taps(sd, lpips_oracle.scale_input(q[:1]))
+    assert np.array_equal(np.array([list(t.shape[1:]) for t in taps]), g["tap_shapes"])
+    np.testing.assert_allclose([float(t.sum()) for t in taps], g["tap_sums"], rtol=2e-5)
+    lp = lpips_oracle.lpips_matrix(sd, lin, q, bank)
+    np.testing.assert_allclose(lp, g["lpips"], atol=2e-6)
+    d, i, _ = lpips_oracle.knn_l2_lpips(sd, lin, bank, q, int(g["batch_size"]))
+    assert np.array_equal(i, g["idx"])
+    np.testing.assert_allclose(d.astype(np.float64), g["dist"], atol=2e-6)
