@@ -74,6 +74,16 @@ SIGNATURES = {
     "gl_dcgan_set_out_bias": (_i, [_p, _p]),
     "gl_dcgan_forward": (_i, [_p, _p, _i64, _p, _p]),
     "gl_dcgan_set_chunk": (_i, [_p, _i64]),
+    "gl_lpips_create": (_i, [_p, _pp]),
+    "gl_lpips_destroy": (_i, [_p]),
+    "gl_lpips_set_conv": (_i, [_p, _i, _p, _p]),
+    "gl_lpips_set_lin": (_i, [_p, _i, _p]),
+    "gl_lpips_set_chunk": (_i, [_p, _i64]),
+    "gl_lpips_feature_dim": (_i64, [_i, _i]),
+    "gl_lpips_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "gl_lpips_features_f32": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
+    "gl_feat_knn_f32": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gl_feat_rows_dist": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
 }
 
 _lib = None
@@ -181,7 +191,7 @@ class Context:
     def event(self):
         return Event(self)
 
-    PROF_TAGS = {"gather_conv": 0, "l2_knn": 1, "convt_rgb": 2, "l2_prepare": 3}
+    PROF_TAGS = {"gather_conv": 0, "l2_knn": 1, "convt_rgb": 2, "l2_prepare": 3, "feat_knn": 4}
 
     def prof_enable(self, on=True):
         check(self.lib.gl_prof_enable(self.handle, 1 if on else 0))

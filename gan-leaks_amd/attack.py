@@ -150,22 +150,24 @@ def unpack_keys(ctx, keys, nq, d, kind="u8"):
     return dist.numpy()[:nq], idx.numpy()[:nq]
 
 
-def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None):
+def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None):
     """nearest bank sample of every query.
 
-    queries : [Q,C,H,W] images, u8 or float; numpy / torch / DeviceArray / Bank
-    bank    : same, or a prepared `Bank` (then `batch_size` truncation applies to len(bank) unless the
-              bank is a shard -- index_base > 0 or reduce_fn given: shards are cut after the global
-              truncation, see shard.py)
-    distance: 'l2' (attack_models/utils.py:161-164).  'l2-lpips' is the reference's fbb default
-              (attack_models/fbb.py:148) and lands with the LPIPS kernels.
+    queries : [Q,C,H,W] images, u8 or float; numpy / torch / DeviceArray / Bank / FeatureBank
+    bank    : same, or a prepared `Bank` / `FeatureBank` (then `batch_size` truncation applies to len(bank)
+              unless the bank is a shard -- index_base > 0 or reduce_fn given: shards are cut after the
+              global truncation, see shard.py)
+    distance: 'l2' (attack_models/utils.py:161-164) or 'l2-lpips' = 0.2*LPIPS + L2, the reference's fbb
+              distance (attack_models/fbb.py:148, utils.py:166-176).  `lpips` is the LpipsModel to use
+              (default: lpips.default_model(), weights from local files).
     returns (dist float32 [Q], idx int64 [Q]); idx < (N // batch_size) * batch_size (fbb.py:77),
     smallest index on ties (fbb.py:86).
     reduce_fn: optional callable(keys DeviceArray) -> keys DeviceArray, the cross-GPU min (shard.py).
     """
-    if distance != "l2":
-        raise NotImplementedError("distance %r: only 'l2' is implemented in this round" % (distance,))
-    if isinstance(bank, Bank):
+    if distance not in ("l2", "l2-lpips"):
+        raise ValueError("distance must be 'l2' or 'l2-lpips', got %r" % (distance,))
+    prepared = isinstance(bank, Bank) or getattr(bank, "kind", None) == "feat"
+    if prepared:
         ctx = bank.ctx
         n_rows = bank.n
         if reduce_fn is None and bank.index_base == 0:
@@ -174,15 +176,27 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
         ctx = ctx or Context.get()
         n_total = len(bank)
         n_rows = (n_total // int(batch_size)) * int(batch_size)
-        if n_rows > 0:
-            if isinstance(bank, DeviceArray):
-                bank = bank.view((n_rows,) + tuple(bank.shape[1:]))
-            else:
-                bank = bank[:n_rows]
-            bank = Bank.from_images(bank, ctx, keep_u8=True)
     if n_rows == 0 and reduce_fn is None:
         # the reference dies in torch.cat([]) (fbb.py:83) with ValueError
         raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
+    if not prepared and n_rows > 0:
+        if isinstance(bank, DeviceArray):
+            bank = bank.view((n_rows,) + tuple(bank.shape[1:]))
+        else:
+            bank = bank[:n_rows]
+
+    if distance == "l2-lpips":
+        from . import lpips as _lp
+        model = lpips or _lp.default_model()
+        fb = bank if prepared else model.features(bank)
+        fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries)
+        keys = _lp.feat_knn_keys(fb, fq, n_rows)
+        if reduce_fn is not None:
+            keys = reduce_fn(keys)
+        return unpack_keys(ctx, keys, fq.n, fb.K, "f32")
+
+    if not prepared:
+        bank = Bank.from_images(bank, ctx, keep_u8=True)
     keys, q, kind = knn_keys(bank, queries, n_rows)
     if reduce_fn is not None:
         keys = reduce_fn(keys)

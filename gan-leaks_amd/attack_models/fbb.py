@@ -65,15 +65,19 @@ def check_args(args):
 _bank_cache = {"key": None, "bank": None}
 
 
-def _cached_bank(syn_imgs, n_rows):
-    """custom_knn is called once per query with the same bank (fbb.py:156-159): prepare it once."""
-    if isinstance(syn_imgs, Bank):
+def _cached_bank(syn_imgs, n_rows, loss):
+    """custom_knn is called once per query with the same bank (fbb.py:156-159): prepare it once
+    (int8 rows for 'l2'; VGG16/LPIPS feature vectors for 'l2-lpips')."""
+    if isinstance(syn_imgs, Bank) or getattr(syn_imgs, "kind", None) == "feat":
         return syn_imgs
     ptr = syn_imgs.data_ptr() if hasattr(syn_imgs, "data_ptr") else (
         syn_imgs.ctypes.data if isinstance(syn_imgs, np.ndarray) else id(syn_imgs))
-    key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows)
+    key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows, loss.distance, id(loss.lpips_model))
     if _bank_cache["key"] != key:
-        _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows], keep_u8=True)
+        if loss.distance == "l2-lpips":
+            _bank_cache["bank"] = loss.lpips_model.features(syn_imgs[:n_rows])
+        else:
+            _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows], keep_u8=True)
         _bank_cache["key"] = key
     return _bank_cache["bank"]
 
@@ -88,9 +92,9 @@ def custom_knn(syn_imgs, sample, loss, args):
     n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
     if n_rows == 0:
         raise ValueError("torch.cat(): expected a non-empty list of Tensors")   # what fbb.py:83 raises
-    bank = _cached_bank(syn_imgs, n_rows)
+    bank = _cached_bank(syn_imgs, n_rows, loss)
     q = sample.unsqueeze(0) if hasattr(sample, "unsqueeze") else np.asarray(sample)[None]
-    dist, idx = attack(q, bank, distance=distance, batch_size=args.BATCH_SIZE)
+    dist, idx = attack(q, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=loss.lpips_model)
     return float(dist[0]), int(idx[0])
 
 
@@ -128,18 +132,21 @@ def main(args):
         pos_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.pos_data_dir, ext='png'), resolution)
         neg_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.neg_data_dir, ext='png'), resolution)
 
-        Loss(distance, if_norm_reg=False)           # announces / validates the distance like fbb.py:148
+        custom_loss = Loss(distance, if_norm_reg=False)          # fbb.py:148 (loads the LPIPS model for 'l2-lpips')
         n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
         if n_rows == 0:
             raise ValueError("torch.cat(): expected a non-empty list of Tensors")
-        bank = Bank.from_images(syn_imgs[:n_rows])
+        if distance == "l2-lpips":
+            bank = custom_loss.lpips_model.features(syn_imgs[:n_rows])
+        else:
+            bank = Bank.from_images(syn_imgs[:n_rows])
 
-        pos_d, pos_i = attack(pos_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE)
+        pos_d, pos_i = attack(pos_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
         pos_loss = pos_d.astype(np.float64).reshape(-1, 1)          # python floats -> float64 [Q,1] (fbb.py:160)
         plt_pos_idx = pos_i.reshape(-1, 1)
         save_files(save_dir, ['pos_loss', 'pos_idx'], [pos_loss, np.arange(len(pos_loss)).reshape(-1, 1)])
 
-        neg_d, neg_i = attack(neg_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE)
+        neg_d, neg_i = attack(neg_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
         neg_loss = neg_d.astype(np.float64).reshape(-1, 1)
         plt_neg_idx = neg_i.reshape(-1, 1)
         # the reference writes arange(len(pos_loss)) here as well (fbb.py:171): kept

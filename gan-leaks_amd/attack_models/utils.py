@@ -74,27 +74,49 @@ class Loss:
     unlike the reference it does not
     build an LPIPS model it never uses (utils.py:157)."""
 
-    def __init__(self, distance, if_norm_reg=False, ctx=None):
+    def __init__(self, distance, if_norm_reg=False, ctx=None, lpips=None):
         if distance not in ("l2", "l2-lpips"):
             raise ValueError("distance must be 'l2' or 'l2-lpips'")
         self.distance = distance
         self.if_norm_reg = if_norm_reg
         self._ctx = ctx
+        self.lpips_model = lpips          # the reference builds ps.PerceptualLoss() here (utils.py:157)
         if distance == "l2":
             print("Use distance: l2")
         else:
             print("Use distance: lpips + l2")
-            raise NotImplementedError("'l2-lpips' needs the LPIPS/VGG16 kernels, which are not part of this round")
+            if self.lpips_model is None:
+                from .. import lpips as _lp
+                self.lpips_model = _lp.default_model()     # local weight files; FileNotFoundError tells which
 
     @property
     def ctx(self):
         if self._ctx is None:
-            self._ctx = Context.get()
+            self._ctx = self.lpips_model.ctx if self.lpips_model is not None else Context.get()
         return self._ctx
+
+    def _finish(self, x_hat, lp, l2):
+        if type(x_hat).__module__.startswith("torch"):
+            import torch
+            l2 = torch.from_numpy(l2).to(x_hat.device)
+            if not np.isscalar(lp):
+                lp = torch.from_numpy(lp).to(x_hat.device)
+        self.loss_lpips = lp
+        self.loss_l2 = l2
+        self.vec_loss = 0.2 * self.loss_lpips + self.loss_l2     # utils.py:176
+        return self.vec_loss
 
     def forward(self, x_hat, x_gt):
         from ..attack import Bank
         ctx = self.ctx
+        if self.distance == "l2-lpips":
+            from .. import lpips as _lp
+            a = self.lpips_model.features(x_hat)
+            g = self.lpips_model.features(x_gt)
+            if g.n not in (1, a.n):
+                raise ValueError("x_gt must hold 1 image or as many as x_hat (broadcast rule of utils.py:168-169)")
+            lp, l2 = _lp.rows_dist(a, g)
+            return self._finish(x_hat, lp, l2)
         a = Bank.from_images(x_hat, ctx, keep_u8=True)
         g = Bank.from_images(x_gt, ctx, keep_u8=True, force_kind="f32" if a.kind == "f32" else None)
         if a.d != g.d:
@@ -106,13 +128,6 @@ class Loss:
             check(ctx.lib.gl_l2_rows_u8(ctx.handle, _p(a.u8.ptr), a.n, _p(g.u8.ptr), g.n, a.d, _p(out.ptr)))
         else:
             check(ctx.lib.gl_l2_rows_f32(ctx.handle, _p(a.rows_f32.ptr), a.n, _p(g.rows_f32.ptr), g.n, a.d, _p(out.ptr)))
-        l2 = out.numpy()[:a.n]
-        if type(x_hat).__module__.startswith("torch"):
-            import torch
-            l2 = torch.from_numpy(l2).to(x_hat.device)
-        self.loss_lpips = 0.0
-        self.loss_l2 = l2
-        self.vec_loss = 0.2 * self.loss_lpips + self.loss_l2     # utils.py:176
-        return self.vec_loss
+        return self._finish(x_hat, 0.0, out.numpy()[:a.n])
 
     __call__ = forward

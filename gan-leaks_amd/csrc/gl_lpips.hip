@@ -1,0 +1,546 @@
+// LPIPS (v0.1, net-lin, VGG16) feature extractor and the 0.2*LPIPS + L2 nearest-neighbour search.
+//   PNetLin.forward   attack_models/lpips_pytorch/models/networks_basic.py:134-181
+//   vgg16 slices      attack_models/lpips_pytorch/models/pretrained_networks.py:96-134
+//   normalize_tensor  attack_models/lpips_pytorch/util/util.py:70-73
+//   Loss('l2-lpips')  attack_models/utils.py:166-176
+//
+// Reformulation: features are computed ONCE per image instead of once per
+// (query, batch) as the reference does, and the distance becomes one dense contraction:
+//   d(q,n) = 0.2 * sum_l mean_hw sum_c w_lc (f^q - f^n)^2 + mean_k (x_q - x_n)^2  =  |V_q - V_n|^2
+//   V = [ sqrt(0.2 w_lc / (H_l W_l)) * f_lc(h,w) / (|f_l(h,w)|_c + 1e-10)  for every tap l, position, channel ;  x_k / sqrt(D) ]
+//   (length 499 712 + 12 288 = 512 000 at 64x64), and |V_q - V_n|^2 = |V_q|^2 + |V_n|^2 - 2 V_q.V_n .
+// All arithmetic is fp32 (fp32 MFMA for the convolutions and the contraction).
+//
+// Convolutions reuse gather_conv_kernel (gl_conv.hip): 3x3 p1 = 9 taps; the first layer (3 input channels)
+// is im2col'ed by the input kernel into one 32-wide K slice (27 values + 5 zeros).
+#include "gl_conv.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int kNumConv = 13;
+const int kCout[kNumConv] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+const int kCin[kNumConv] = {3, 64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512};
+// after conv index i: 1 = LPIPS tap, 2 = tap then 2x2 max-pool
+const int kAfter[kNumConv] = {0, 2, 0, 2, 0, 0, 2, 0, 0, 2, 0, 0, 1};
+const int kTapC[5] = {64, 128, 256, 512, 512};
+
+__constant__ float c_shift[3] = {-.030f, -.088f, -.188f};   // networks_basic.py:115
+__constant__ float c_scale[3] = {.458f, .448f, .450f};      // networks_basic.py:116
+
+__device__ __forceinline__ float load_pixel(const uint8_t *p, const float *lut) { return lut[*p]; }
+__device__ __forceinline__ float load_pixel(const float *p, const float *) { return *p; }
+
+// image [n][3][H][W] (u8 codes or fp32 in [-1,1]) -> scaled, 3x3-im2col'ed NHWC [n][H][W][32]:
+// channel (ky*3+kx)*3 + c = ((x - shift_c) / scale_c) at (y+ky-1, x+kx-1), 0 outside the image (the conv's zero
+// padding acts on the scaled tensor), channels 27..31 = 0.
+template <typename T>
+__global__ void __launch_bounds__(256) vgg_input_kernel(const T *__restrict__ img, int64_t n, int H, int W, float *__restrict__ out)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);   // attack_models/utils.py:82
+    __syncthreads();
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * H * W) return;
+    const int64_t im = gid / (H * W);
+    const int rem = (int)(gid - im * (H * W));
+    const int y = rem / W, x = rem - y * W;
+    float v[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) v[k] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.0f;
+                if (ok) t = __fdiv_rn(__fsub_rn(load_pixel(img + ((im * 3 + c) * H + yy) * (int64_t)W + xx, lut), c_shift[c]), c_scale[c]);
+                v[(ky * 3 + kx) * 3 + c] = t;
+            }
+        }
+    float4 *o = reinterpret_cast<float4 *>(out + gid * 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+}
+
+// 2x2 / stride 2 max-pool, NHWC, C % 4 == 0
+__global__ void __launch_bounds__(256) maxpool2_nhwc_kernel(const float *__restrict__ in, int64_t n, int H, int W, int C, float *__restrict__ out)
+{
+    const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+    const int64_t total = n * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t r = i / C4;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int64_t im = r / Ho;
+        const float4 *p = reinterpret_cast<const float4 *>(in + (((im * H + 2 * yo) * W + 2 * xo) * (int64_t)C)) + c4;
+        const float4 a = p[0], b = p[C4], c = p[(int64_t)W * C4], d = p[(int64_t)W * C4 + C4];
+        float4 m;
+        m.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+        m.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+        m.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+        m.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+        reinterpret_cast<float4 *>(out)[i] = m;
+    }
+}
+
+// one wave per position: f / (sqrt(sum_c f^2) + 1e-10) * coef_c  ->  V[img][off + pos*C + c]   (C % 64 == 0)
+__global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict__ f, int64_t n, int HW, int C, const float *__restrict__ coef,
+                                                        float *__restrict__ V, int64_t ldv, int64_t off)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t total = n * HW;
+    for (int64_t pos = wave; pos < total; pos += nwaves) {
+        const float *src = f + pos * C;
+        float ss = 0.0f;
+        for (int c = lane; c < C; c += 64) { const float t = src[c]; ss = fmaf(t, t, ss); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = 1.0f / (sqrtf(ss) + 1e-10f);        // eps outside the sqrt (util.py:72-73)
+        const int64_t im = pos / HW;
+        float *dst = V + im * ldv + off + (pos - im * HW) * C;
+        for (int c = lane; c < C; c += 64) dst[c] = src[c] * inv * coef[c];
+    }
+}
+
+// image part of V: x_k / sqrt(D)
+template <typename T>
+__global__ void __launch_bounds__(256) image_part_kernel(const T *__restrict__ img, int64_t n, int64_t D, float inv_sqrt_d, float *__restrict__ V, int64_t ldv,
+                                                         int64_t off)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
+    __syncthreads();
+    const int64_t total = n * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t im = i / D;
+        V[im * ldv + off + (i - im * D)] = load_pixel(img + i, lut) * inv_sqrt_d;
+    }
+}
+
+// |V_row|^2: one workgroup per row, fp32 chains per thread, fp64 combine
+__global__ void __launch_bounds__(256) row_sqnorm_kernel(const float *__restrict__ V, int64_t n, int64_t K, float *__restrict__ out)
+{
+    __shared__ double red[256];
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float4 *p = reinterpret_cast<const float4 *>(V + r * K);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int64_t k = threadIdx.x; k < K / 4; k += 256) {
+            const float4 v = p[k];
+            s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+        }
+        red[threadIdx.x] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[r] = (float)red[0];
+        __syncthreads();
+    }
+}
+
+// per-row |V_a - V_b|^2 split at K_lp: out_lp = (sum over the LPIPS part) / 0.2, out_l2 = sum over the image part.
+// (Loss.forward's loss_lpips / loss_l2 vectors, attack_models/utils.py:173-176)
+__global__ void __launch_bounds__(256) feat_rows_dist_kernel(const float *__restrict__ Va, int64_t b, const float *__restrict__ Vb, int64_t b_gt, int64_t K,
+                                                             int64_t K_lp, float *__restrict__ out_lp, float *__restrict__ out_l2)
+{
+    __shared__ double red[2][256];
+    for (int64_t r = blockIdx.x; r < b; r += gridDim.x) {
+        const float *pa = Va + r * K;
+        const float *pb = Vb + (b_gt == 1 ? 0 : r) * K;
+        float s_lp = 0.f, s_l2 = 0.f;
+        for (int64_t k = threadIdx.x; k < K_lp; k += 256) { const float t = pb[k] - pa[k]; s_lp = fmaf(t, t, s_lp); }
+        for (int64_t k = K_lp + threadIdx.x; k < K; k += 256) { const float t = pb[k] - pa[k]; s_l2 = fmaf(t, t, s_l2); }
+        red[0][threadIdx.x] = s_lp;
+        red[1][threadIdx.x] = s_l2;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { out_lp[r] = (float)(red[0][0] / 0.2); out_l2[r] = (float)red[1][0]; }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pairwise |V_q - V_n|^2 + argmin on the fp32 matrix cores.
+// C[n][q] = V_n . V_q  (v_mfma_f32_32x32x2_f32), tile 128 bank rows x 128 queries, 4 waves as 2 x 2,
+// K slices of 32 floats double buffered in LDS via global_load_lds -- the main loop of gather_conv_kernel
+// with two plain row operands -- and the epilogue of l2_knn_i8_kernel:
+// dist = max(|V_q|^2 + |V_n|^2 - 2 C, 0), key = float_bits(dist) << 32 | global index, atomicMin.
+// ---------------------------------------------------------------------------------------------
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int FT = 128, FBK = 32, FOPER = FT * FBK * 4;
+
+__device__ __forceinline__ int fswz(int r) { return (r >> 1) & 7; }
+
+__global__ void __launch_bounds__(256, 2)
+feat_knn_f32_kernel(const float *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                    const float *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K,
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
+    const int qt = (int)(id % (unsigned)q_tiles), nt = (int)(id / (unsigned)q_tiles);
+    const int64_t n0 = (int64_t)nt * FT, q0 = (int64_t)qt * FT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wq = wave & 1;
+    const int rsub = lane >> 3, slot = lane & 7;
+
+    const float *a_src[4], *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + rsub;
+        int64_t gn = n0 + r, gq = q0 + r;
+        if (gn >= n_rows) gn = n_rows - 1;      // clamped duplicates are masked in the epilogue
+        if (gq >= nq) gq = nq - 1;
+        a_src[i] = bank + gn * K + (slot ^ fswz(r)) * 4;
+        b_src[i] = query + gq * K + (slot ^ fswz(r)) * 4;
+    }
+    auto stage = [&](int64_t k0, char *buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl_glds16(a_src[i] + k0, buf + (wave * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + k0, buf + FOPER + (wave * 4 + i) * 1024);
+    };
+
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int64_t nk = K / FBK;
+    stage(0, smem);
+    const int frow = lane & 31, fh = lane >> 5;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        char *cur = smem + (kt & 1) * 2 * FOPER;
+        if (kt + 1 < nk) stage((kt + 1) * FBK, smem + ((kt + 1) & 1) * 2 * FOPER);
+        const char *la = cur + (wn * 64) * (FBK * 4);
+        const char *lb = cur + FOPER + (wq * 64) * (FBK * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int chunk = 2 * g + fh;
+            v4f a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = i * 32 + frow;
+                a[i] = *reinterpret_cast<const v4f *>(la + r * (FBK * 4) + ((chunk ^ fswz(r)) << 4));
+                b[i] = *reinterpret_cast<const v4f *>(lb + r * (FBK * 4) + ((chunk ^ fswz(r)) << 4));
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C layout 32x32: column (query) = lane & 31, row (bank) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t q = q0 + wq * 64 + j * 32 + frow;
+        const float qn = q < nq ? query_norm[q] : 0.0f;
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (n < n_rows) {
+                    const float d = fmaxf(fmaf(-2.0f, acc[i][j][r], __fadd_rn(qn, bank_norm[n])), 0.0f);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
+                    best = key < best ? key : best;
+                }
+            }
+        const unsigned long long o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (fh == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+    }
+}
+
+}  // namespace
+
+struct gl_lpips {
+    gl_ctx *ctx;
+    float *w[kNumConv];       // packed conv weights
+    float *bias[kNumConv];
+    float *ones;              // 512 ones (epilogue scale)
+    float *lin[5];            // raw lin weights (host-checked >= 0)
+    std::vector<float> lin_host[5];
+    bool have_w[kNumConv], have_lin[5];
+    // workspace for `chunk` images of H x W
+    int64_t chunk, ws_imgs;
+    int ws_H, ws_W;
+    float *ws_in, *ws_a, *ws_b, *ws_coef;
+};
+
+namespace {
+
+int lp_upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
+{
+    if (!*dev) GL_HIP(hipMalloc((void **)dev, host.size() * sizeof(float)));
+    GL_HIP(hipMemcpyAsync(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
+{
+    int64_t want = l->chunk > 0 ? l->chunk : 1024;
+    if (n < want) want = n;
+    if (want <= l->ws_imgs && H == l->ws_H && W == l->ws_W) return GL_OK;
+    GL_HIP(hipStreamSynchronize(l->ctx->stream));
+    (void)hipFree(l->ws_in); (void)hipFree(l->ws_a); (void)hipFree(l->ws_b);
+    l->ws_in = l->ws_a = l->ws_b = nullptr;
+    l->ws_imgs = 0;
+    const size_t px = (size_t)want * H * W;
+    GL_HIP(hipMalloc((void **)&l->ws_in, px * 32 * 4));
+    GL_HIP(hipMalloc((void **)&l->ws_a, px * 64 * 4));      // largest activation: H x W x 64
+    GL_HIP(hipMalloc((void **)&l->ws_b, px * 64 * 4));
+    l->ws_imgs = want; l->ws_H = H; l->ws_W = W;
+    return GL_OK;
+}
+
+int stream_blocks(int64_t items)
+{
+    int64_t b = gl_ceil_div(items, 256);
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+template <typename T>
+int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
+{
+    GL_REQUIRE(l && n >= 0, "gl_lpips_features: bad argument");
+    GL_REQUIRE(H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0, "gl_lpips_features: H, W must be multiples of 16 (four 2x2 pools), got %dx%d", H, W);
+    for (int i = 0; i < kNumConv; ++i)
+        if (!l->have_w[i]) { gl_set_error("gl_lpips_features: VGG16 conv %d not loaded", i); return GL_ERR_STATE; }
+    for (int i = 0; i < 5; ++i)
+        if (!l->have_lin[i]) { gl_set_error("gl_lpips_features: lin%d not loaded", i); return GL_ERR_STATE; }
+    if (n == 0) return GL_OK;
+    GL_REQUIRE(img_dev && V_dev && norms_dev, "gl_lpips_features: NULL device pointer");
+    gl_ctx *ctx = l->ctx;
+    int rc = lp_workspace(l, n, H, W);
+    if (rc != GL_OK) return rc;
+    const int64_t D = 3ll * H * W;
+    int64_t K_lp = 0;
+    {
+        int h = H, w = W;
+        for (int t = 0; t < 5; ++t) { K_lp += (int64_t)kTapC[t] * h * w; h /= 2; w /= 2; }
+    }
+    const int64_t K = K_lp + D;
+    // per-tap coefficients sqrt(0.2 * w_c / (h*w))
+    {
+        std::vector<float> coef;
+        int h = H, w = W;
+        for (int t = 0; t < 5; ++t) {
+            for (int c = 0; c < kTapC[t]; ++c) coef.push_back((float)std::sqrt(0.2 * (double)l->lin_host[t][c] / ((double)h * w)));
+            h /= 2; w /= 2;
+        }
+        rc = lp_upload(ctx, &l->ws_coef, coef);
+        if (rc != GL_OK) return rc;
+    }
+
+    for (int64_t i0 = 0; i0 < n; i0 += l->ws_imgs) {
+        const int64_t m = (n - i0 < l->ws_imgs) ? n - i0 : l->ws_imgs;
+        float *Vc = V_dev + i0 * K;
+        hipLaunchKernelGGL(vgg_input_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W, l->ws_in);
+        GL_LAUNCH_CHECK();
+        const float *cur = l->ws_in;
+        float *bufs[2] = {l->ws_a, l->ws_b};
+        int which = 0, h = H, w = W;
+        int64_t off = 0, coef_off = 0;
+        for (int ci = 0; ci < kNumConv; ++ci) {
+            GlGatherConv p = {};
+            p.in = cur; p.positions = m * h * w; p.H = h; p.W = w;
+            p.wpack = l->w[ci]; p.cols = kCout[ci]; p.cols_pad = kCout[ci];
+            if (ci == 0) { p.Cin = 32; p.ntaps = 1; p.tap_dy[0] = 1; p.tap_dx[0] = 1; }
+            else {
+                p.Cin = kCin[ci]; p.ntaps = 9;
+                uint32_t dy = 0, dx = 0;
+                for (int t = 0; t < 9; ++t) { dy |= (uint32_t)(t / 3) << (2 * t); dx |= (uint32_t)(t % 3) << (2 * t); }
+                p.tap_dy[0] = dy; p.tap_dx[0] = dx;
+            }
+            p.out = bufs[which]; p.Ho = h; p.Wo = w; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0;
+            p.scale = l->ones; p.shift = l->bias[ci]; p.cmod = kCout[ci]; p.act = 1; p.zero = ctx->zero_page;
+            rc = gl_launch_gather_conv(ctx, p, 1);
+            if (rc != GL_OK) return rc;
+            cur = bufs[which];
+            which ^= 1;
+            if (kAfter[ci] >= 1) {
+                const int C = kCout[ci];
+                hipLaunchKernelGGL(lpips_tap_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream, cur, m, h * w, C,
+                                   l->ws_coef + coef_off, Vc, K, off);
+                GL_LAUNCH_CHECK();
+                off += (int64_t)C * h * w;
+                coef_off += C;
+            }
+            if (kAfter[ci] == 2) {
+                const int C = kCout[ci];
+                hipLaunchKernelGGL(maxpool2_nhwc_kernel, dim3((unsigned)stream_blocks(m * (h / 2) * (w / 2) * (C / 4))), dim3(256), 0, ctx->stream, cur, m, h, w, C,
+                                   bufs[which]);
+                GL_LAUNCH_CHECK();
+                cur = bufs[which];
+                which ^= 1;
+                h /= 2; w /= 2;
+            }
+        }
+        hipLaunchKernelGGL(image_part_kernel<T>, dim3((unsigned)stream_blocks(m * D)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D,
+                           (float)(1.0 / std::sqrt((double)D)), Vc, K, K_lp);
+        GL_LAUNCH_CHECK();
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, Vc, m, K, norms_dev + i0);
+        GL_LAUNCH_CHECK();
+    }
+    return GL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gl_lpips_create(gl_ctx *ctx, gl_lpips **out)
+{
+    GL_REQUIRE(ctx && out, "gl_lpips_create: NULL argument");
+    gl_lpips *l = new gl_lpips();
+    l->ctx = ctx;
+    for (int i = 0; i < kNumConv; ++i) { l->w[i] = l->bias[i] = nullptr; l->have_w[i] = false; }
+    for (int i = 0; i < 5; ++i) { l->lin[i] = nullptr; l->have_lin[i] = false; }
+    l->ones = nullptr;
+    l->chunk = 0; l->ws_imgs = 0; l->ws_H = l->ws_W = 0;
+    l->ws_in = l->ws_a = l->ws_b = l->ws_coef = nullptr;
+    std::vector<float> one(512, 1.0f);
+    int rc = lp_upload(ctx, &l->ones, one);
+    if (rc != GL_OK) { delete l; return rc; }
+    *out = l;
+    return GL_OK;
+}
+
+int gl_lpips_destroy(gl_lpips *l)
+{
+    if (!l) return GL_OK;
+    (void)hipStreamSynchronize(l->ctx->stream);
+    for (int i = 0; i < kNumConv; ++i) { (void)hipFree(l->w[i]); (void)hipFree(l->bias[i]); }
+    for (int i = 0; i < 5; ++i) (void)hipFree(l->lin[i]);
+    (void)hipFree(l->ones); (void)hipFree(l->ws_in); (void)hipFree(l->ws_a); (void)hipFree(l->ws_b); (void)hipFree(l->ws_coef);
+    delete l;
+    return GL_OK;
+}
+
+int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass)
+{
+    GL_REQUIRE(l && images_per_pass >= 0, "gl_lpips_set_chunk: bad argument");
+    l->chunk = images_per_pass;
+    return GL_OK;
+}
+
+int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *bias)
+{
+    GL_REQUIRE(l && w && bias && conv_index >= 0 && conv_index < kNumConv, "gl_lpips_set_conv: bad argument");
+    const int co_n = kCout[conv_index], ci_n = kCin[conv_index];
+    auto Wt = [&](int co, int ci, int ky, int kx) { return w[(((int64_t)co * ci_n + ci) * 3 + ky) * 3 + kx]; };
+    std::vector<float> pk;
+    if (conv_index == 0) {
+        pk.assign((size_t)co_n * 32, 0.0f);     // K = 32: (ky*3+kx)*3 + c, matching vgg_input_kernel
+        for (int co = 0; co < co_n; ++co)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    for (int c = 0; c < 3; ++c) pk[(size_t)co * 32 + (ky * 3 + kx) * 3 + c] = Wt(co, c, ky, kx);
+    } else {
+        const int K = 9 * ci_n;
+        pk.assign((size_t)co_n * K, 0.0f);
+        for (int co = 0; co < co_n; ++co)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx)
+                    for (int ci = 0; ci < ci_n; ++ci) pk[(size_t)co * K + gl_conv_k_index(ky * 3 + kx, ci, 9)] = Wt(co, ci, ky, kx);
+    }
+    int rc = lp_upload(l->ctx, &l->w[conv_index], pk);
+    if (rc != GL_OK) return rc;
+    std::vector<float> b(bias, bias + co_n);
+    rc = lp_upload(l->ctx, &l->bias[conv_index], b);
+    if (rc != GL_OK) return rc;
+    l->have_w[conv_index] = true;
+    return GL_OK;
+}
+
+int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w)
+{
+    GL_REQUIRE(l && w && layer >= 0 && layer < 5, "gl_lpips_set_lin: bad argument");
+    for (int c = 0; c < kTapC[layer]; ++c)
+        GL_REQUIRE(w[c] >= 0.0f, "gl_lpips_set_lin: lin%d weight %d is negative (%g); the |V_q - V_n|^2 form needs w >= 0", layer, c, (double)w[c]);
+    l->lin_host[layer].assign(w, w + kTapC[layer]);
+    l->have_lin[layer] = true;
+    return GL_OK;
+}
+
+int64_t gl_lpips_feature_dim(int H, int W)
+{
+    if (H < 16 || W < 16 || H % 16 || W % 16) return -1;
+    int64_t k = 3ll * H * W;
+    int h = H, w = W;
+    for (int t = 0; t < 5; ++t) { k += (int64_t)kTapC[t] * h * w; h /= 2; w /= 2; }
+    return k;
+}
+
+int gl_lpips_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
+{
+    return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V_dev, norms_dev);
+}
+
+int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
+{
+    return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V_dev, norms_dev);
+}
+
+int gl_feat_knn_f32(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
+                    const float *query_norm_dev, int64_t nq, int64_t K, uint64_t *keys_dev)
+{
+    GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K > 0 && K % FBK == 0, "gl_feat_knn_f32: bad sizes (K must be a multiple of %d)", FBK);
+    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn_f32: global index does not fit 32 bits");
+    if (n_rows == 0 || nq == 0) return GL_OK;
+    GL_REQUIRE(bank_V_dev && bank_norm_dev && query_V_dev && query_norm_dev && keys_dev, "gl_feat_knn_f32: NULL device pointer");
+    GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V_dev) | reinterpret_cast<uintptr_t>(query_V_dev)) & 15) == 0, "gl_feat_knn_f32: rows must be 16-byte aligned");
+    const int64_t q_tiles = gl_ceil_div(nq, FT), n_tiles = gl_ceil_div(n_rows, FT);
+    GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn_f32: grid too large");
+    static bool attr_set = false;
+    const int lds = 4 * FOPER;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
+    hipLaunchKernelGGL(feat_knn_f32_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, bank_V_dev, bank_norm_dev, n_rows, index_base,
+                       query_V_dev, query_norm_dev, nq, K, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,
+                      float *out_l2_dev)
+{
+    GL_REQUIRE(ctx && b >= 0 && K > 0 && K_lp >= 0 && K_lp <= K, "gl_feat_rows_dist: bad sizes");
+    GL_REQUIRE(b_gt == 1 || b_gt == b, "gl_feat_rows_dist: x_gt must hold 1 row or %lld rows, got %lld", (long long)b, (long long)b_gt);
+    if (b == 0) return GL_OK;
+    GL_REQUIRE(V_hat_dev && V_gt_dev && out_lpips_dev && out_l2_dev, "gl_feat_rows_dist: NULL device pointer");
+    hipLaunchKernelGGL(feat_rows_dist_kernel, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, ctx->stream, V_hat_dev, b, V_gt_dev, b_gt, K, K_lp,
+                       out_lpips_dev, out_l2_dev);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // extern "C"

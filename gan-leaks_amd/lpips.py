@@ -1,0 +1,157 @@
+"""LPIPS (v0.1, net-lin, VGG16) on the device: counterpart of the reference's
+`lpips_pytorch.PerceptualLoss(model='net-lin', net='vgg')` (attack_models/lpips_pytorch/__init__.py:9-32)
+as used by `Loss('l2-lpips')` (attack_models/utils.py:157,166-176).
+
+Weights are read from LOCAL files only (the reference downloads the VGG16 backbone through torchvision,
+pretrained_networks.py:99 -- there is no network here):
+  * backbone: a torchvision `vgg16` state dict (keys `features.{0,2,...,28}.{weight,bias}`) or the bare
+    `features` state dict (`{0,2,...}.{weight,bias}`)
+  * lin layers: the reference's `attack_models/lpips_pytorch/pretrained_models/v0.1/vgg.pth`
+    (keys `lin{0..4}.model.1.weight`)
+Default locations come from $GANLEAKS_VGG16_PATH and $GANLEAKS_LPIPS_LIN_PATH.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from ._lib import Context, DeviceArray, check
+from .attack import _to_device_rows, encode_if_lattice
+
+_p = ctypes.c_void_p
+VGG16_CONV_KEYS = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+LPIPS_CHANNELS = [64, 128, 256, 512, 512]
+
+
+def _np(v):
+    if type(v).__module__.startswith("torch"):
+        v = v.detach().cpu().numpy()
+    return np.ascontiguousarray(v, dtype=np.float32)
+
+
+class FeatureBank:
+    """V rows + |V|^2 of a set of images, resident in HBM (gl_lpips_features_*)."""
+
+    def __init__(self, ctx, V, norms, n, K, K_lp, index_base=0):
+        self.ctx, self.V, self.norms, self.n, self.K, self.K_lp = ctx, V, norms, int(n), int(K), int(K_lp)
+        self.index_base = int(index_base)
+        self.kind = "feat"
+
+    def __len__(self):
+        return self.n
+
+
+class LpipsModel:
+    def __init__(self, ctx=None):
+        self.ctx = ctx or Context.get()
+        h = _p()
+        check(self.ctx.lib.gl_lpips_create(self.ctx.handle, ctypes.byref(h)))
+        self._handle = h
+        self._loaded = False
+
+    def __del__(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                self.ctx.lib.gl_lpips_destroy(self._handle)
+            except Exception:  # noqa: BLE001
+                pass
+
+    def load_state_dicts(self, vgg_state_dict, lin_state_dict):
+        lib = self.ctx.lib
+        for i, k in enumerate(VGG16_CONV_KEYS):
+            for prefix in ("features.%d." % k, "%d." % k):
+                if prefix + "weight" in vgg_state_dict:
+                    break
+            else:
+                raise KeyError("VGG16 state dict has no conv %d (features.%d.weight)" % (k, k))
+            w, b = _np(vgg_state_dict[prefix + "weight"]), _np(vgg_state_dict[prefix + "bias"])
+            if w.ndim != 4 or w.shape[2:] != (3, 3) or b.shape != (w.shape[0],):
+                raise ValueError("VGG16 conv %d has shape %s / %s" % (k, w.shape, b.shape))
+            check(lib.gl_lpips_set_conv(self._handle, i, w.ctypes.data_as(_p), b.ctypes.data_as(_p)))
+        for i in range(5):
+            key = "lin%d.model.1.weight" % i
+            w = _np(lin_state_dict[key] if key in lin_state_dict else lin_state_dict["lin%d" % i]).reshape(-1)
+            if w.shape != (LPIPS_CHANNELS[i],):
+                raise ValueError("lin%d has %d weights, expected %d" % (i, w.size, LPIPS_CHANNELS[i]))
+            check(lib.gl_lpips_set_lin(self._handle, i, w.ctypes.data_as(_p)))
+        self._loaded = True
+        return self
+
+    @classmethod
+    def from_files(cls, vgg_path=None, lin_path=None, ctx=None):
+        vgg_path = vgg_path or os.environ.get("GANLEAKS_VGG16_PATH")
+        lin_path = lin_path or os.environ.get("GANLEAKS_LPIPS_LIN_PATH")
+        if not vgg_path or not lin_path or not os.path.exists(vgg_path) or not os.path.exists(lin_path):
+            raise FileNotFoundError(
+                "'l2-lpips' needs local weight files: a torchvision VGG16 state dict (GANLEAKS_VGG16_PATH) and the LPIPS lin "
+                "weights attack_models/lpips_pytorch/pretrained_models/v0.1/vgg.pth (GANLEAKS_LPIPS_LIN_PATH). "
+                "The reference downloads the backbone (pretrained_networks.py:99); no download is attempted here.")
+        import torch
+        vgg = torch.load(vgg_path, map_location="cpu", weights_only=True)
+        lin = torch.load(lin_path, map_location="cpu", weights_only=True)
+        return cls(ctx).load_state_dicts(vgg, lin)
+
+    def set_chunk(self, images_per_pass):
+        check(self.ctx.lib.gl_lpips_set_chunk(self._handle, int(images_per_pass)))
+
+    def features(self, images, index_base=0):
+        """images [n,3,H,W] (u8, or float in [-1,1]) -> FeatureBank."""
+        if not self._loaded:
+            raise RuntimeError("LpipsModel: weights not loaded")
+        ctx = self.ctx
+        shape = tuple(images.shape)
+        if len(shape) != 4 or shape[1] != 3:
+            raise ValueError("LPIPS needs images of shape [n,3,H,W], got %s" % (shape,))
+        n, _, H, W = shape
+        K = int(ctx.lib.gl_lpips_feature_dim(H, W))
+        if K < 0:
+            raise ValueError("LPIPS path needs H and W to be multiples of 16, got %dx%d" % (H, W))
+        rows = _to_device_rows(ctx, images)
+        V = ctx.empty((max(n, 1), K), np.float32)
+        norms = ctx.empty((max(n, 1),), np.float32)
+        if rows.dtype == np.float32:
+            u8, bad = encode_if_lattice(ctx, rows)
+            if bad == 0:
+                rows = u8
+        if rows.dtype == np.uint8:
+            check(ctx.lib.gl_lpips_features_u8(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+        else:
+            check(ctx.lib.gl_lpips_features_f32(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+        return FeatureBank(ctx, V, norms, n, K, K - 3 * H * W, index_base)
+
+
+_default = {"model": None}
+
+
+def set_default_model(model):
+    _default["model"] = model
+
+
+def default_model():
+    if _default["model"] is None:
+        _default["model"] = LpipsModel.from_files()
+    return _default["model"]
+
+
+def feat_knn_keys(bank, queries, n_rows=None, keys=None):
+    ctx = bank.ctx
+    if queries.K != bank.K:
+        raise ValueError("feature lengths differ: %d vs %d" % (queries.K, bank.K))
+    n_rows = bank.n if n_rows is None else int(n_rows)
+    if keys is None:
+        keys = ctx.empty((max(queries.n, 1),), np.uint64)
+        check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), queries.n))
+    check(ctx.lib.gl_feat_knn_f32(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
+                                  _p(queries.norms.ptr), queries.n, bank.K, _p(keys.ptr)))
+    return keys
+
+
+def rows_dist(a, g):
+    """(lpips [b], l2 [b]) between FeatureBanks a (x_hat) and g (x_gt, 1 row or b rows)."""
+    ctx = a.ctx
+    lp = ctx.empty((max(a.n, 1),), np.float32)
+    l2 = ctx.empty((max(a.n, 1),), np.float32)
+    check(ctx.lib.gl_feat_rows_dist(ctx.handle, _p(a.V.ptr), a.n, _p(g.V.ptr), g.n, a.K, a.K_lp, _p(lp.ptr), _p(l2.ptr)))
+    return lp.numpy()[:a.n], l2.numpy()[:a.n]

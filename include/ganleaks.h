@@ -39,6 +39,7 @@ typedef enum gl_status {
 
 typedef struct gl_ctx gl_ctx;       /* opaque: device + stream + scratch */
 typedef struct gl_dcgan gl_dcgan;   /* opaque: packed DCGAN / WGAN-GP generator */
+typedef struct gl_lpips gl_lpips;   /* opaque: VGG16 + LPIPS v0.1 lin layers */
 
 /* ---------------------------------------------------------------- library / context */
 int gl_abi_version(void);
@@ -70,6 +71,7 @@ int gl_event_elapsed_ms(void *start, void *stop, float *out_ms);   /* synchronis
 #define GL_PROF_L2_KNN 1        /* int8-MFMA pairwise L2 + argmin */
 #define GL_PROF_CONVT_RGB 2     /* generator tail: ConvT -> 3 channels + tanh + quantise */
 #define GL_PROF_L2_PREPARE 3    /* u8 -> biased int8 + norms */
+#define GL_PROF_FEAT_KNN 4      /* fp32-MFMA pairwise |V_q - V_n|^2 + argmin (l2-lpips) */
 int gl_prof_enable(gl_ctx *ctx, int on);
 int gl_prof_read(gl_ctx *ctx, int tag, double *out_total_ms, int64_t *out_launches);
 int gl_prof_reset(gl_ctx *ctx);
@@ -145,6 +147,32 @@ int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias_host);   /* gen.4.bias 
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev);
 /* images per internal pass (activations for that many images stay resident); 0 = default */
 int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass);
+
+/* ---------------------------------------------------------------- LPIPS (0.2 * LPIPS + L2, the reference's fbb distance) */
+/* PerceptualLoss(model='net-lin', net='vgg') (attack_models/lpips_pytorch/__init__.py:9-32) -> PNetLin
+ * (models/networks_basic.py:134-181) on torchvision's VGG16 `features` (models/pretrained_networks.py:96-134).
+ * Features are computed once per image into a vector V with |V_q - V_n|^2 = 0.2*LPIPS(q,n) + mean((q-n)^2)
+ * (attack_models/utils.py:176); see gan-leaks_amd/csrc/gl_lpips.hip. */
+int gl_lpips_create(gl_ctx *ctx, gl_lpips **out);
+int gl_lpips_destroy(gl_lpips *l);
+/* conv_index 0..12 = torchvision vgg16().features convs {0,2,5,7,10,12,14,17,19,21,24,26,28}: weight [C_out][C_in][3][3], bias [C_out]; HOST pointers */
+int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w_host, const float *bias_host);
+/* layer 0..4 = lin{layer}.model.1.weight of pretrained_models/v0.1/vgg.pth, [C] floats, all >= 0; HOST pointer */
+int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w_host);
+int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass);
+/* length of V for H x W images: sum_l C_l H_l W_l + 3 H W  (512 000 at 64 x 64); -1 if H or W is not a multiple of 16 */
+int64_t gl_lpips_feature_dim(int H, int W);
+/* images [n][3][H][W] (8-bit codes, or fp32 in [-1,1]) -> V_dev [n][K] fp32 and norms_dev [n] = |V|^2 */
+int gl_lpips_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev);
+int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev);
+/* keys[q] = min(keys[q], (float_bits(max(|V_q|^2 + |V_n|^2 - 2 V_q.V_n, 0)) << 32) | (index_base + n)), n < n_rows.
+ * custom_knn (attack_models/fbb.py:73-88) with Loss('l2-lpips'); unpack with gl_keys_unpack_f32. */
+int gl_feat_knn_f32(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
+                    const float *query_norm_dev, int64_t nq, int64_t K, uint64_t *keys_dev);
+/* Loss('l2-lpips').forward: per row, out_lpips = LPIPS and out_l2 = mean((y-x)^2) between V_hat[i] and V_gt[b_gt == 1 ? 0 : i];
+ * K_lp = K - 3 H W is the length of the LPIPS part of V */
+int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,
+                      float *out_l2_dev);
 
 #ifdef __cplusplus
 }

@@ -50,8 +50,11 @@ def test_fbb_main_and_eval_roc(tmp_path, monkeypatch, synth, oracle):
     _, _, _, oauc, oap, oprec = oracle.plot_roc(-pos_loss, -neg_loss)
     assert abs(auc - oauc) < 1e-12 and abs(ap - oap) < 1e-12 and prec == oprec
     assert (out / "roc.png").exists()
-    # default distance is the reference's 'l2-lpips', which is announced as not built yet
+    # default distance is the reference's 'l2-lpips'; without local weight files it says which are missing
     args2 = fbb.parse_arguments(["--syn_data_path", str(tmp_path / "syn"), "--pos_data_dir", str(tmp_path / "pos"),
                                  "--neg_data_dir", str(tmp_path / "neg"), "--resolution", "16", "--BATCH_SIZE", "64"])
-    with pytest.raises(NotImplementedError):
+    monkeypatch.delenv("GANLEAKS_VGG16_PATH", raising=False)
+    from ganleaks_amd import lpips
+    lpips.set_default_model(None)
+    with pytest.raises(FileNotFoundError):
         fbb.main(args2)

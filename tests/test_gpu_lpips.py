@@ -1,0 +1,130 @@
+"""GPU parity tests of the 'l2-lpips' path (VGG16 + LPIPS on fp32 MFMA, |V_q - V_n|^2 contraction + argmin)
+against vectors produced by the reference's PNetLin (tests/golden/lpips_*.npz) and the fp64 oracle.
+Tolerance: 1e-4 on distances (north_star); measured ~1e-6.  Backbone weights are seeded random (the ImageNet
+VGG16 weights are not available offline), lin weights are the reference's vendored ones."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import ganleaks_amd
+    return ganleaks_amd
+
+
+@pytest.fixture(scope="module")
+def lin(golden_dir):
+    z = np.load(os.path.join(golden_dir, "lpips_lin_v0.1.npz"))
+    return {"lin%d" % i: z["lin%d" % i] for i in range(5)}
+
+
+@pytest.fixture(scope="module")
+def model(gl, synth, lin):
+    from ganleaks_amd.lpips import LpipsModel
+    return LpipsModel().load_state_dicts(synth.vgg16_state_dict(7), lin)
+
+
+def _case(g, synth):
+    case = synth.attack_case(int(g["seed"]), int(g["n_bank"]), int(g["n_pos"]), int(g["n_neg"]), int(g["res"]), sigma=20.0)
+    return case["bank"], np.concatenate([case["pos"], case["neg"]])
+
+
+@pytest.mark.parametrize("name", ["lpips_res32", "lpips_res64"])
+def test_attack_l2_lpips_matches_reference(name, gl, synth, model, golden_dir):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    bank, q = _case(g, synth)
+    dist, idx = gl.attack(q, bank, distance="l2-lpips", batch_size=int(g["batch_size"]), lpips=model)
+    assert np.array_equal(idx, g["idx"])
+    err = np.abs(dist.astype(np.float64) - g["dist"]).max()
+    assert err < ATOL, err
+    assert err < 5e-6, err       # what fp32 actually delivers
+
+
+@pytest.mark.parametrize("name", ["lpips_res32"])
+def test_loss_forward_and_custom_knn(name, gl, synth, model, oracle, golden_dir):
+    from ganleaks_amd.attack_models.fbb import custom_knn
+    from ganleaks_amd.attack_models.utils import Loss
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    bank, q = _case(g, synth)
+    loss = Loss("l2-lpips", lpips=model)
+    bs = int(g["batch_size"])
+    v = loss(bank[:bs], q[:1])                                   # the reference's call shape: [B] vs [1]
+    assert np.abs(loss.loss_lpips - g["lpips"][0, :bs]).max() < 5e-6
+    l2 = (oracle.ssd_u8(bank[:bs], q[0]).astype(np.float64) * oracle.l2_scale(q[0].size)).astype(np.float32)
+    assert np.abs(loss.loss_l2 - l2).max() < 1e-6
+    assert np.abs(v - (0.2 * g["lpips"][0, :bs] + l2)).max() < 5e-6
+    bank_f = oracle.dequantize_u8(bank)
+    q_f = oracle.dequantize_u8(q)
+    args = types.SimpleNamespace(BATCH_SIZE=bs)
+    for k in (0, 5):
+        d, i = custom_knn(bank_f, q_f[k], loss, args)
+        assert isinstance(d, float) and isinstance(i, int)
+        assert i == int(g["idx"][k]) and abs(d - float(g["dist"][k])) < 5e-6
+
+
+def test_vs_fp64_oracle_ragged_and_shards(gl, synth, model, lin, oracle):
+    """sizes that do not fill tiles; off-lattice float images; shard merge"""
+    import lpips_oracle
+    from ganleaks_amd.lpips import feat_knn_keys
+    from ganleaks_amd.attack import unpack_keys
+    sd = synth.vgg16_state_dict(7)
+    linl = [lin["lin%d" % i] for i in range(5)]
+    case = synth.attack_case(91, 37, 3, 2, 16, sigma=25.0)
+    bank = case["bank"]
+    q = np.concatenate([case["pos"], case["neg"]])
+    od, oi, tot = lpips_oracle.knn_l2_lpips(sd, linl, oracle.dequantize_u8(bank), oracle.dequantize_u8(q), 8)
+    d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=8, lpips=model)
+    assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
+    assert i.max() < 32
+    # off-lattice floats go through the fp32 feature kernel
+    rng = np.random.default_rng(0)
+    bf = np.clip(oracle.dequantize_u8(bank) + rng.normal(0, 0.01, bank.shape).astype(np.float32), -1, 1)
+    qf = np.clip(oracle.dequantize_u8(q) + rng.normal(0, 0.01, q.shape).astype(np.float32), -1, 1)
+    od, oi, _ = lpips_oracle.knn_l2_lpips(sd, linl, bf, qf, 8)
+    d, i = gl.attack(qf, bf, distance="l2-lpips", batch_size=8, lpips=model)
+    assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
+    # shards
+    fq = model.features(q)
+    keys = None
+    for lo, hi in ((16, 32), (0, 16)):
+        keys = feat_knn_keys(model.features(bank[lo:hi], index_base=lo), fq, keys=keys)
+    ds, is_ = unpack_keys(gl.Context.get(), keys, fq.n, fq.K, "f32")
+    d0, i0 = gl.attack(q, bank, distance="l2-lpips", batch_size=8, lpips=model)
+    assert np.array_equal(is_, i0) and np.array_equal(ds, d0)
+
+
+def test_fbb_main_default_distance_with_local_weights(tmp_path, monkeypatch, gl, synth, lin, model):
+    """the reference's default: Loss('l2-lpips') (fbb.py:148), weights from local files"""
+    import torch
+    import PIL.Image
+    from ganleaks_amd import lpips
+    from ganleaks_amd.attack_models import fbb
+    torch.save({"features.%s" % k: torch.from_numpy(v) for k, v in synth.vgg16_state_dict(7).items()}, tmp_path / "vgg16.pth")
+    torch.save({"lin%d.model.1.weight" % i: torch.from_numpy(lin["lin%d" % i]).view(1, -1, 1, 1) for i in range(5)}, tmp_path / "vgg_lin.pth")
+    monkeypatch.setenv("GANLEAKS_VGG16_PATH", str(tmp_path / "vgg16.pth"))
+    monkeypatch.setenv("GANLEAKS_LPIPS_LIN_PATH", str(tmp_path / "vgg_lin.pth"))
+    lpips.set_default_model(None)
+    case = synth.attack_case(95, 40, 5, 4, 32, sigma=20.0)
+    for name in ("bank", "pos", "neg"):
+        d = tmp_path / name
+        d.mkdir()
+        for k, im in enumerate(case[name]):
+            PIL.Image.fromarray(im.transpose(1, 2, 0)).save(d / ("image_%02d.png" % k))
+    monkeypatch.chdir(tmp_path)
+    args = fbb.parse_arguments(["--exp_name", "lp", "--syn_data_path", str(tmp_path / "bank"), "--pos_data_dir", str(tmp_path / "pos"),
+                                "--neg_data_dir", str(tmp_path / "neg"), "--resolution", "32", "--BATCH_SIZE", "16"])
+    assert args.distance == "l2-lpips"
+    fbb.main(args)
+    out = tmp_path / "fbb_attack" / "lp"
+    d_ref, i_ref = gl.attack(case["pos"], case["bank"], distance="l2-lpips", batch_size=16, lpips=model)
+    assert np.array_equal(np.load(out / "pos_nn_idx.npy")[:, 0], i_ref)
+    assert np.allclose(np.load(out / "pos_loss.npy")[:, 0], d_ref.astype(np.float64), atol=1e-7)
+    lpips.set_default_model(None)
