@@ -49,6 +49,8 @@ def main():
     ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(16, usable cores))")
     ap.add_argument("--check-queries", type=int, default=64, help="queries checked against the oracle after the run")
+    ap.add_argument("--distance", default="l2", choices=["l2", "l2-lpips"],
+                    help="l2 = BASELINE configs[1] (default, the headline); l2-lpips = configs[2] (0.2*LPIPS+L2; needs ~2 MB of HBM per image)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,6 +102,20 @@ def main():
     queries_u8 = np.concatenate([pos, neg])
     q_dev = ctx.to_device(queries_u8.reshape(Q, D))
 
+    lp_model = None
+    F_VGG_PER_IMG = 2.0 * 1252.8e6          # 13 convs at 64x64
+    if args.distance == "l2-lpips":
+        from ganleaks_amd.lpips import LpipsModel
+        lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
+        lp_model = LpipsModel(ctx).load_state_dicts(synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
+        KF = int(lib.gl_lpips_feature_dim(64, 64))
+        need_gb = (n_loc + Q) * KF * 4 / 1e9
+        log("[rank %d] l2-lpips: feature vectors need %.1f GB of HBM" % (rank, need_gb))
+        bank_V = ctx.empty((n_loc, KF), np.float32)
+        bank_Vn = ctx.empty((n_loc,), np.float32)
+        q_V = ctx.empty((Q, KF), np.float32)
+        q_Vn = ctx.empty((Q,), np.float32)
+
     stride = int(lib.gl_l2_row_stride(D))
     bank_u8 = ctx.empty((n_loc, D), np.uint8)
     bank_i8 = ctx.empty((n_loc, stride), np.int8)
@@ -125,15 +141,24 @@ def main():
         check(lib.gl_dcgan_forward(gen._handle, p(z_dev.ptr), n_loc, p(0), p(bank_u8.ptr)))
         if timed_phases is not None:
             ev[1].record()
-        check(lib.gl_l2_prepare(ctx.handle, p(bank_u8.ptr), n_loc, D, p(bank_i8.ptr), p(bank_nrm.ptr)))
-        check(lib.gl_l2_prepare(ctx.handle, p(q_dev.ptr), Q, D, p(q_i8.ptr), p(q_nrm.ptr)))
-        check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
-        check(lib.gl_l2_knn_i8(ctx.handle, p(bank_i8.ptr), p(bank_nrm.ptr), n_loc, lo, p(q_i8.ptr), p(q_nrm.ptr), Q, D, p(keys.ptr)))
+        if lp_model is None:
+            check(lib.gl_l2_prepare(ctx.handle, p(bank_u8.ptr), n_loc, D, p(bank_i8.ptr), p(bank_nrm.ptr)))
+            check(lib.gl_l2_prepare(ctx.handle, p(q_dev.ptr), Q, D, p(q_i8.ptr), p(q_nrm.ptr)))
+            check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
+            check(lib.gl_l2_knn_i8(ctx.handle, p(bank_i8.ptr), p(bank_nrm.ptr), n_loc, lo, p(q_i8.ptr), p(q_nrm.ptr), Q, D, p(keys.ptr)))
+        else:
+            check(lib.gl_lpips_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
+            check(lib.gl_lpips_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
+            check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
+            check(lib.gl_feat_knn_f32(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr)))
         if timed_phases is not None:
             ev[2].record()
         if world > 1:
             dist.all_reduce(keys_t, op=dist.ReduceOp.MIN)
-        check(lib.gl_keys_unpack(ctx.handle, p(keys.ptr), Q, D, p(dist_dev.ptr), p(idx_dev.ptr)))
+        if lp_model is None:
+            check(lib.gl_keys_unpack(ctx.handle, p(keys.ptr), Q, D, p(dist_dev.ptr), p(idx_dev.ptr)))
+        else:
+            check(lib.gl_keys_unpack_f32(ctx.handle, p(keys.ptr), Q, p(dist_dev.ptr), p(idx_dev.ptr)))
         check(lib.gl_memcpy_d2h(ctx.handle, out_dist.ctypes.data_as(p), p(dist_dev.ptr), Q * 4))
         check(lib.gl_memcpy_d2h(ctx.handle, out_idx.ctypes.data_as(p), p(idx_dev.ptr), Q * 8))
         if timed_phases is not None:
@@ -186,13 +211,15 @@ def main():
 
     kernels = [
         # all five ConvTranspose layers run in gather_conv (the 3-channel tail as a 48-column scatter-form GEMM)
-        kernel_entry("gather_conv", n_loc * (F_GATHER_PER_IMG + F_RGB_PER_IMG), "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1e12),
+        kernel_entry("gather_conv", n_loc * (F_GATHER_PER_IMG + F_RGB_PER_IMG) + (0 if lp_model is None else (n_loc + Q) * F_VGG_PER_IMG), "mfma",
+                     PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1e12),
         kernel_entry("l2_knn", 2.0 * Q * n_loc * D, "mfma", PEAK_I8_MFMA_TOPS, "TOP/s", 1e12),
+        kernel_entry("feat_knn", 0 if lp_model is None else 2.0 * Q * n_loc * KF, "mfma", PEAK_F32_MFMA_TFLOPS, "TFLOP/s", 1e12),
         # col2im + tanh + quantise: reads P [1024][48] fp32, writes 12288 codes per image
         kernel_entry("convt_rgb", n_loc * (1024 * 48 * 4 + 12288.0), "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
         kernel_entry("l2_prepare", 2.0 * (n_loc + Q) * D, "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
     ]
-    kernels = [k for k in kernels if k]
+    kernels = [k for k in kernels if k and k["alg_per_launch"] > 0]
     dominant = max(kernels, key=lambda k: k["avg_ms"] * k["launches"])
     roofline = {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     roofline["kernel"] = dominant["kernel"]
@@ -202,7 +229,20 @@ def main():
     # ---------------------------------------------------------------- parity check against the oracle (untimed)
     parity = None
     auroc = None
-    if args.check_queries > 0:
+    if args.check_queries > 0 and lp_model is not None and world == 1:
+        # l2-lpips: fp64 oracle on a small sub-problem (8 queries x the first 256 bank samples)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import lpips_oracle
+        import oracle as np_oracle
+        lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
+        sub_bank = bank_u8.numpy()[:256].reshape(256, 3, 64, 64)
+        sel = np.linspace(0, Q - 1, 8).astype(np.int64)
+        od, oi, _ = lpips_oracle.knn_l2_lpips(synth.vgg16_state_dict(7), [lin["lin%d" % i] for i in range(5)], np_oracle.dequantize_u8(sub_bank),
+                                              np_oracle.dequantize_u8(queries_u8[sel]), 64)
+        gd, gi = gl.attack(queries_u8[sel], sub_bank, distance="l2-lpips", batch_size=64, lpips=lp_model)
+        parity = {"queries_checked": 8, "bank_checked": 256, "idx_equal": bool(np.array_equal(gi, oi)),
+                  "max_abs_dist_err": float(np.abs(gd.astype(np.float64) - od).max())}
+    elif args.check_queries > 0 and lp_model is None:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import c_oracle
         nchk = min(args.check_queries, Q)
@@ -223,7 +263,7 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_queries > 0:
+    if rank == 0 and world == 1 and args.cpu_queries > 0 and lp_model is None:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import torch_port
         usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -257,8 +297,11 @@ def main():
             "metric": "attack query-images/sec (10k queries x 100k samples) + AUROC delta vs ref",
             "value": round(value, 2), "unit": "query-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (generator) + i8->i32 exact (distance)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)", "queries": Q, "bank": N,
+            "dtype": "f32 (generator) + i8->i32 exact (distance)" if lp_model is None else "f32 (generator, VGG16, LPIPS contraction)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)" if lp_model is None else
+                       "BASELINE configs[2] shape: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",
+                       "queries": Q, "bank": N,
                        "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d, queries replicated, "
                        "all-reduce(min) of %d packed keys" % (world, Q) if world > 1 else "single GPU"},
             "roofline": roofline,
