@@ -74,6 +74,13 @@ SIGNATURES = {
     "gl_dcgan_set_out_bias": (_i, [_p, _p]),
     "gl_dcgan_forward": (_i, [_p, _p, _i64, _p, _p]),
     "gl_dcgan_set_chunk": (_i, [_p, _i64]),
+    "gl_pggan_create": (_i, [_p, _i, _i, _i, _pp]),
+    "gl_pggan_destroy": (_i, [_p]),
+    "gl_pggan_set_initial": (_i, [_p, _p, _p, _p, _p]),
+    "gl_pggan_set_block": (_i, [_p, _i, _p, _p, _p, _p]),
+    "gl_pggan_set_rgb": (_i, [_p, _i, _p, _p]),
+    "gl_pggan_set_chunk": (_i, [_p, _i64]),
+    "gl_pggan_forward": (_i, [_p, _p, _i64, _i, ctypes.c_float, _p, _p]),
     "gl_lpips_create": (_i, [_p, _pp]),
     "gl_lpips_destroy": (_i, [_p]),
     "gl_lpips_set_conv": (_i, [_p, _i, _p, _p]),

@@ -5,10 +5,11 @@
 #include "gl_common.h"
 
 struct GlGatherConv {
-    // input activations, NHWC fp32: [n_img][H][W][Cin]
+    // input activations, NHWC fp32: [n_img][H >> up][W >> up][Cin]
     const float *in;
     int64_t positions;          // n_img * H * W   (GEMM M: one row per base-grid position)
-    int H, W, Cin;
+    int H, W, Cin;              // H, W: the convolution's input grid
+    int up;                     // 1: `in` is stored at (H/2) x (W/2) and read through nearest-neighbour 2x upsampling
     // packed weights: [phases][cols_pad][K] fp32, K = ntaps * Cin contiguous, ordered by gl_conv_k_index
     const float *wpack;
     int cols;                   // real GEMM columns (output channels per position)
@@ -23,7 +24,7 @@ struct GlGatherConv {
     // planar != 0: write column-major out[c * ld_planar + position] instead (single phase, identity position map)
     int planar;
     int64_t ld_planar;
-    // epilogue: v = acc * scale[c % cmod] + shift[c % cmod]; act 0 none, 1 relu
+    // epilogue: v = acc * scale[c % cmod] + shift[c % cmod]; act 0 none, 1 ReLU, 2 LeakyReLU(0.2)
     const float *scale, *shift;
     int cmod;
     int act;

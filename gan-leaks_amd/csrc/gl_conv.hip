@@ -64,10 +64,12 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 
     // ---- per-thread staging bookkeeping: one 16-B chunk of A_PER activation rows and B_PER weight rows
     const int rsub = lane >> 3, slot = lane & 7;
-    int64_t a_off[A_PER];     // element offset of (img, y, x, 0)
-    int a_y[A_PER], a_x[A_PER];   // y = -1000000 marks a row beyond `positions`
+    int a_img[A_PER];             // first source pixel of the row's image (img * Hs * Ws)
+    int a_y[A_PER], a_x[A_PER];   // position in the convolution's input grid; y = -1000000 marks a row beyond `positions`
     int a_chunk[A_PER];
     const float *b_src[B_PER];
+    const int up = p.up;          // 1: the input grid is the nearest-neighbour 2x upsampling of the stored tensor
+    const int Hs = p.H >> up, Ws = p.W >> up;
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int r = (wave * A_PER + i) * 8 + rsub;
@@ -78,11 +80,11 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
             const int rem = (int)(pos - img * HW);
             a_y[i] = rem / p.W;
             a_x[i] = rem - a_y[i] * p.W;
-            a_off[i] = pos * p.Cin;
+            a_img[i] = (int)(img * Hs * Ws);
         } else {
             a_y[i] = -1000000;
             a_x[i] = 0;
-            a_off[i] = 0;
+            a_img[i] = 0;
         }
     }
 #pragma unroll
@@ -99,12 +101,12 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
         const int ci0 = (kt / p.ntaps) * BK;
         const int dy = (int)((tdy >> (2 * tap)) & 3u) - 1;
         const int dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
-        const int64_t shift = ((int64_t)dy * p.W + dx) * p.Cin + ci0;
 #pragma unroll
         for (int i = 0; i < A_PER; ++i) {
             const int yy = a_y[i] + dy, xx = a_x[i] + dx;
             const bool ok = (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
-            const float *src = ok ? p.in + a_off[i] + shift + a_chunk[i] : p.zero;
+            const int64_t pix = a_img[i] + (yy >> up) * Ws + (xx >> up);
+            const float *src = ok ? p.in + pix * p.Cin + ci0 + a_chunk[i] : p.zero;
             gl_glds16(src, buf + (wave * A_PER + i) * 1024);
         }
 #pragma unroll
@@ -179,6 +181,7 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     // branch-free store tail for full tiles (per-store branches make hipcc wait vmcnt(0) between stores);
     // only the last, ragged position tile takes the checked variant.
     const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
+    const float neg_slope = p.act == 2 ? 0.2f : 1.0f;     // act 2: LeakyReLU(0.2) = max(v, 0.2 v)
     auto store_tile = [&](auto checked) {
         constexpr bool CHECK = decltype(checked)::value;
 #pragma unroll
@@ -196,10 +199,10 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
                     for (int g = 0; g < 4; ++g) {
                         const int o = o32[i][4 * g];
                         float4 v;
-                        v.x = fmaxf(fmaf(acc[i][j][4 * g + 0], sc, sh), relu_floor);
-                        v.y = fmaxf(fmaf(acc[i][j][4 * g + 1], sc, sh), relu_floor);
-                        v.z = fmaxf(fmaf(acc[i][j][4 * g + 2], sc, sh), relu_floor);
-                        v.w = fmaxf(fmaf(acc[i][j][4 * g + 3], sc, sh), relu_floor);
+                        v.x = fmaf(acc[i][j][4 * g + 0], sc, sh); v.x = fmaxf(fmaxf(v.x, v.x * neg_slope), relu_floor);
+                        v.y = fmaf(acc[i][j][4 * g + 1], sc, sh); v.y = fmaxf(fmaxf(v.y, v.y * neg_slope), relu_floor);
+                        v.z = fmaf(acc[i][j][4 * g + 2], sc, sh); v.z = fmaxf(fmaxf(v.z, v.z * neg_slope), relu_floor);
+                        v.w = fmaf(acc[i][j][4 * g + 3], sc, sh); v.w = fmaxf(fmaxf(v.w, v.w * neg_slope), relu_floor);
                         if (c_ok && (!CHECK || o >= 0)) *reinterpret_cast<float4 *>(colp + o) = v;
                     }
             } else {
@@ -209,7 +212,8 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = o32[i][r];
-                        const float v = fmaxf(fmaf(acc[i][j][r], sc, sh), relu_floor);
+                        float v = fmaf(acc[i][j][r], sc, sh);
+                        v = fmaxf(fmaxf(v, v * neg_slope), relu_floor);
                         if (c_ok && (!CHECK || o >= 0)) colp[(int64_t)o * p.cols] = v;
                     }
             }
@@ -313,7 +317,9 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
     GL_REQUIRE(p.Cin % BK == 0, "gather_conv: Cin=%d must be a multiple of %d", p.Cin, BK);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv: bad phases/taps");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.wpack) & 15) == 0, "gather_conv: unaligned operand");
-    GL_REQUIRE((p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv: more than 2^31 output positions in one launch");
+    GL_REQUIRE((p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31) && p.positions < (1ll << 31),
+               "gather_conv: more than 2^31 positions in one launch");
+    GL_REQUIRE(p.up == 0 || (p.up == 1 && p.H % 2 == 0 && p.W % 2 == 0), "gather_conv: up must be 0 or 1 (even H, W)");
     if (p.planar)
         GL_REQUIRE(phases == 1 && p.omul == 1 && p.Ho == p.H && p.Wo == p.W && p.positions % 4 == 0 && p.ld_planar % 4 == 0 &&
                        p.ld_planar >= p.positions && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0,

@@ -1,0 +1,360 @@
+// Progressive-GAN generator behind the C ABI (gan_models/pggan/model_torch.py:49-88):
+//   initial : PixelNorm -> ConvTranspose2d(z, C, 4,1,0)+bias -> LeakyReLU(0.2) -> WSConv3x3 -> LeakyReLU -> PixelNorm
+//   step s  : nearest x2 -> [WSConv3x3 -> LeakyReLU -> PixelNorm] x 2          (ConvBlock, :33-47)
+//   output  : tanh(alpha * rgb[steps](out) + (1 - alpha) * rgb[steps-1](upscaled))   (fade_in, :71-72)
+//             steps == 0: rgb[0](out) without tanh (:78-79)
+// WSConv2d (:8-22) scales its INPUT by sqrt(2/(C_in k^2)); the factor is folded into the packed weights.
+// Every convolution runs in gather_conv_kernel (fp32 MFMA): 3x3 = 9 taps, the nearest-neighbour upsampling
+// is fused into the gather (GlGatherConv::up), toRGB = 1 tap with 3 (padded to 64) columns.
+#include "gl_conv.h"
+#include <cmath>
+#include <vector>
+
+namespace {
+
+const double kFactors[9] = {1, 1, 1, 1, 1.0 / 2, 1.0 / 4, 1.0 / 8, 1.0 / 16, 1.0 / 32};   // model_torch.py:6
+constexpr int kBlocks = 8;
+
+// rows: x / sqrt(mean(x^2) + 1e-8), written zero-padded to dpad.  One wave per row.
+__global__ void __launch_bounds__(256) pixelnorm_rows_kernel(const float *__restrict__ in, int64_t n, int d, int dpad, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const float *src = in + row * d;
+    float ss = 0.0f;
+    for (int c = lane; c < d; c += 64) { const float t = src[c]; ss = fmaf(t, t, ss); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = 1.0f / sqrtf(ss / (float)d + 1e-8f);
+    for (int c = lane; c < dpad; c += 64) out[row * dpad + c] = c < d ? src[c] * inv : 0.0f;
+}
+
+// NHWC, in place: one wave per position
+__global__ void __launch_bounds__(256) pixelnorm_nhwc_kernel(float *__restrict__ x, int64_t positions, int C)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t pos = wave; pos < positions; pos += nwaves) {
+        float *p = x + pos * C;
+        float ss = 0.0f;
+        for (int c = lane; c < C; c += 64) { const float t = p[c]; ss = fmaf(t, t, ss); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = 1.0f / sqrtf(ss / (float)C + 1e-8f);
+        for (int c = lane; c < C; c += 64) p[c] *= inv;
+    }
+}
+
+__device__ __forceinline__ uint32_t quantize_half(float x)
+{
+    // gan_models/pggan/train.py:238: gen(...) * 0.5 + 0.5, then ToPILImage mul(255).byte()
+    float t = __fmul_rn(__fadd_rn(__fmul_rn(x, 0.5f), 0.5f), 255.0f);
+    t = fminf(fmaxf(truncf(t), 0.0f), 255.0f);
+    return (uint32_t)(int)t;
+}
+
+// a: [n][R][R][nc] (rgb of the last block); b: [n][R/2][R/2][nc] (rgb of its input, read through nearest x2) or NULL.
+// out NCHW.  use_tanh = 0 for steps == 0.
+__global__ void __launch_bounds__(256) pggan_output_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, int R, int nc, float alpha,
+                                                           int use_tanh, float *__restrict__ out_f32, uint8_t *__restrict__ out_u8)
+{
+    const int64_t total = n * nc * R * R;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % R);
+        int64_t r = i / R;
+        const int y = (int)(r % R);
+        r /= R;
+        const int c = (int)(r % nc);
+        const int64_t im = r / nc;
+        float v = a[((im * R + y) * R + x) * nc + c];
+        if (use_tanh) {
+            if (b) {
+                const int Rh = R / 2;
+                const float u = b[((im * Rh + (y >> 1)) * Rh + (x >> 1)) * nc + c];
+                v = __fadd_rn(__fmul_rn(alpha, v), __fmul_rn(1.0f - alpha, u));
+            }
+            v = tanhf(v);
+        }
+        if (out_f32) out_f32[i] = v;
+        if (out_u8) out_u8[i] = (uint8_t)quantize_half(v);
+    }
+}
+
+int pg_upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
+{
+    if (*dev) { (void)hipStreamSynchronize(ctx->stream); (void)hipFree(*dev); *dev = nullptr; }
+    GL_HIP(hipMalloc((void **)dev, host.size() * sizeof(float)));
+    GL_HIP(hipMemcpyAsync(*dev, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int pad_to(int v, int m) { return (int)gl_ceil_div(v, m) * m; }
+int cols_pad_of(int cols) { return cols % 128 == 0 ? cols : pad_to(cols, 64); }
+
+// WSConv weight [Cout][Cin][k][k] (k = 1 or 3) -> packed [cols_pad][k*k*Cin] with the input scale folded in
+std::vector<float> pack_ws(const float *w, int cout, int cin, int k)
+{
+    const int taps = k * k, K = taps * cin, cp = cols_pad_of(cout);
+    const double scale = std::sqrt(2.0 / ((double)cin * k * k));
+    std::vector<float> pk((size_t)cp * K, 0.0f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t) pk[(size_t)co * K + gl_conv_k_index(t, ci, taps)] = (float)((double)w[((size_t)co * cin + ci) * taps + t] * scale);
+    return pk;
+}
+
+}  // namespace
+
+struct gl_pggan {
+    gl_ctx *ctx;
+    int z_dim, z_pad, C, nc;
+    int cin[kBlocks], cout[kBlocks];
+    float *w_init, *b_init, *w_i3, *b_i3;
+    float *w_blk[kBlocks][2], *b_blk[kBlocks][2];
+    float *w_rgb[kBlocks + 1], *b_rgb[kBlocks + 1];
+    bool have_init, have_blk[kBlocks], have_rgb[kBlocks + 1];
+    float *ones;
+    int64_t chunk, ws_imgs;
+    size_t ws_act_elems, ws_rgb_elems;
+    float *ws_z, *ws_buf[3], *ws_rgb[2];
+};
+
+namespace {
+
+int rgb_cin(const gl_pggan *g, int j) { return j == 0 ? g->C : g->cout[j - 1]; }
+
+int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int Cin, const float *w, const float *bias, int cols, int ntaps, int act,
+            float *out)
+{
+    GlGatherConv p = {};
+    p.in = in; p.positions = m * H * W; p.H = H; p.W = W; p.Cin = Cin; p.up = up;
+    p.wpack = w; p.cols = cols; p.cols_pad = cols_pad_of(cols); p.ntaps = ntaps;
+    if (ntaps == 1) { p.tap_dy[0] = 1; p.tap_dx[0] = 1; }
+    else {
+        uint32_t dy = 0, dx = 0;
+        for (int t = 0; t < 9; ++t) { dy |= (uint32_t)(t / 3) << (2 * t); dx |= (uint32_t)(t % 3) << (2 * t); }
+        p.tap_dy[0] = dy; p.tap_dx[0] = dx;
+    }
+    p.out = out; p.Ho = H; p.Wo = W; p.omul = 1;
+    p.scale = g->ones; p.shift = bias; p.cmod = cols; p.act = act; p.zero = g->ctx->zero_page;
+    return gl_launch_gather_conv(g->ctx, p, 1);
+}
+
+int pg_pixelnorm(gl_pggan *g, float *x, int64_t positions, int C)
+{
+    int64_t blocks = gl_ceil_div(positions, 4);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pixelnorm_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream, x, positions, C);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gl_pggan_create(gl_ctx *ctx, int z_dim, int in_channels, int img_channels, gl_pggan **out)
+{
+    GL_REQUIRE(ctx && out, "gl_pggan_create: NULL argument");
+    GL_REQUIRE(z_dim > 0 && z_dim <= 4096 && in_channels >= 32 && in_channels % 32 == 0 && img_channels > 0 && img_channels <= 4,
+               "gl_pggan_create: unsupported sizes z_dim=%d in_channels=%d (multiple of 32) img_channels=%d", z_dim, in_channels, img_channels);
+    gl_pggan *g = new gl_pggan();
+    g->ctx = ctx; g->z_dim = z_dim; g->z_pad = pad_to(z_dim, 32); g->C = in_channels; g->nc = img_channels;
+    for (int i = 0; i < kBlocks; ++i) {
+        g->cin[i] = (int)(in_channels * kFactors[i]);
+        g->cout[i] = (int)(in_channels * kFactors[i + 1]);
+        g->w_blk[i][0] = g->w_blk[i][1] = g->b_blk[i][0] = g->b_blk[i][1] = nullptr;
+        g->have_blk[i] = false;
+    }
+    for (int j = 0; j <= kBlocks; ++j) { g->w_rgb[j] = g->b_rgb[j] = nullptr; g->have_rgb[j] = false; }
+    g->w_init = g->b_init = g->w_i3 = g->b_i3 = nullptr;
+    g->have_init = false;
+    g->ones = nullptr;
+    g->chunk = 0; g->ws_imgs = 0; g->ws_act_elems = 0; g->ws_rgb_elems = 0;
+    g->ws_z = nullptr; g->ws_buf[0] = g->ws_buf[1] = g->ws_buf[2] = nullptr; g->ws_rgb[0] = g->ws_rgb[1] = nullptr;
+    std::vector<float> one(16 * (size_t)in_channels, 1.0f);
+    int rc = pg_upload(ctx, &g->ones, one);
+    if (rc != GL_OK) { delete g; return rc; }
+    *out = g;
+    return GL_OK;
+}
+
+int gl_pggan_destroy(gl_pggan *g)
+{
+    if (!g) return GL_OK;
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(g->w_init); (void)hipFree(g->b_init); (void)hipFree(g->w_i3); (void)hipFree(g->b_i3); (void)hipFree(g->ones);
+    for (int i = 0; i < kBlocks; ++i)
+        for (int k = 0; k < 2; ++k) { (void)hipFree(g->w_blk[i][k]); (void)hipFree(g->b_blk[i][k]); }
+    for (int j = 0; j <= kBlocks; ++j) { (void)hipFree(g->w_rgb[j]); (void)hipFree(g->b_rgb[j]); }
+    (void)hipFree(g->ws_z);
+    for (int k = 0; k < 3; ++k) (void)hipFree(g->ws_buf[k]);
+    for (int k = 0; k < 2; ++k) (void)hipFree(g->ws_rgb[k]);
+    delete g;
+    return GL_OK;
+}
+
+int gl_pggan_set_chunk(gl_pggan *g, int64_t images_per_pass)
+{
+    GL_REQUIRE(g && images_per_pass >= 0, "gl_pggan_set_chunk: bad argument");
+    g->chunk = images_per_pass;
+    return GL_OK;
+}
+
+/* initial.1.{weight [z][C][4][4], bias [C]} and initial.3.{conv.weight [C][C][3][3], bias [C]} */
+int gl_pggan_set_initial(gl_pggan *g, const float *convt_w, const float *convt_b, const float *ws_w, const float *ws_b)
+{
+    GL_REQUIRE(g && convt_w && convt_b && ws_w && ws_b, "gl_pggan_set_initial: NULL argument");
+    const int C = g->C, K = g->z_pad;
+    std::vector<float> pk((size_t)16 * C * K, 0.0f);   // GEMM [16*C][z_pad]: column (ky*4+kx)*C + co -> NHWC 4x4xC
+    for (int ci = 0; ci < g->z_dim; ++ci)
+        for (int co = 0; co < C; ++co)
+            for (int t = 0; t < 16; ++t) pk[((size_t)t * C + co) * K + ci] = convt_w[((size_t)ci * C + co) * 16 + t];
+    int rc = pg_upload(g->ctx, &g->w_init, pk);
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_init, std::vector<float>(convt_b, convt_b + C));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->w_i3, pack_ws(ws_w, C, C, 3));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_i3, std::vector<float>(ws_b, ws_b + C));
+    if (rc != GL_OK) return rc;
+    g->have_init = true;
+    return GL_OK;
+}
+
+/* prog_blocks.{block}.conv{1,2}.{conv.weight, bias} */
+int gl_pggan_set_block(gl_pggan *g, int block, const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv2_b)
+{
+    GL_REQUIRE(g && block >= 0 && block < kBlocks && conv1_w && conv1_b && conv2_w && conv2_b, "gl_pggan_set_block: bad argument");
+    const int ci = g->cin[block], co = g->cout[block];
+    GL_REQUIRE(co >= 1, "gl_pggan_set_block: block %d has no channels at in_channels=%d", block, g->C);
+    if (ci % 32 != 0 || co % 32 != 0) { g->have_blk[block] = false; return GL_OK; }   // too narrow for the 32-channel K slices: forward() refuses this depth
+    int rc = pg_upload(g->ctx, &g->w_blk[block][0], pack_ws(conv1_w, co, ci, 3));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_blk[block][0], std::vector<float>(conv1_b, conv1_b + co));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->w_blk[block][1], pack_ws(conv2_w, co, co, 3));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_blk[block][1], std::vector<float>(conv2_b, conv2_b + co));
+    if (rc != GL_OK) return rc;
+    g->have_blk[block] = true;
+    return GL_OK;
+}
+
+/* rgb_layers.{j}.{conv.weight [nc][C_j][1][1], bias [nc]}; j = 0 is initial_rgb */
+int gl_pggan_set_rgb(gl_pggan *g, int j, const float *w, const float *b)
+{
+    GL_REQUIRE(g && j >= 0 && j <= kBlocks && w && b, "gl_pggan_set_rgb: bad argument");
+    const int ci = rgb_cin(g, j);
+    GL_REQUIRE(ci >= 1, "gl_pggan_set_rgb: layer %d has no input channels", j);
+    if (ci % 32 != 0) { g->have_rgb[j] = false; return GL_OK; }
+    int rc = pg_upload(g->ctx, &g->w_rgb[j], pack_ws(w, g->nc, ci, 1));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_rgb[j], std::vector<float>(b, b + g->nc));
+    if (rc != GL_OK) return rc;
+    g->have_rgb[j] = true;
+    return GL_OK;
+}
+
+/* z_dev [n][z_dim] -> [n][nc][R][R], R = 4 * 2^steps.  out_f32_dev = Generator.forward(x, steps, alpha);
+ * out_u8_dev = the bytes pggan/train.py:238-246 writes (x*0.5+0.5, mul(255).byte()).  Either may be NULL. */
+int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, float alpha, float *out_f32_dev, uint8_t *out_u8_dev)
+{
+    GL_REQUIRE(g && n >= 0 && steps >= 0 && steps <= kBlocks, "gl_pggan_forward: bad argument (steps in [0,8])");
+    if (!g->have_init) { gl_set_error("gl_pggan_forward: initial block not loaded"); return GL_ERR_STATE; }
+    for (int s = 0; s < steps; ++s) {
+        GL_REQUIRE(g->cin[s] % 32 == 0 && g->cout[s] % 32 == 0, "gl_pggan_forward: block %d has %d -> %d channels; the K slices need multiples of 32", s,
+                   g->cin[s], g->cout[s]);
+        if (!g->have_blk[s]) { gl_set_error("gl_pggan_forward: prog_blocks.%d not loaded", s); return GL_ERR_STATE; }
+    }
+    if (!g->have_rgb[steps] || (steps > 0 && !g->have_rgb[steps - 1])) { gl_set_error("gl_pggan_forward: rgb_layers.%d/%d not loaded", steps, steps - 1); return GL_ERR_STATE; }
+    if (n == 0) return GL_OK;
+    GL_REQUIRE(z_dev && (out_f32_dev || out_u8_dev), "gl_pggan_forward: NULL z or no output requested");
+    gl_ctx *ctx = g->ctx;
+    const int R = 4 << steps, nc = g->nc, C = g->C;
+
+    // workspace: three activation buffers sized for the largest layer of this depth
+    size_t act = (size_t)16 * C;
+    {
+        int hw = 16;
+        for (int s = 0; s < steps; ++s) {
+            hw *= 4;
+            const size_t a = (size_t)hw * (g->cout[s] > 0 ? g->cout[s] : 1);
+            if (a > act) act = a;
+        }
+    }
+    int64_t want = g->chunk > 0 ? g->chunk : (int64_t)((768ull << 20) / (act * 4));   // ~768 MiB per buffer by default
+    if (want < 1) want = 1;
+    if (want > n) want = n;
+    const size_t rgb_elems = (size_t)R * R * nc;
+    if (want > g->ws_imgs || act > g->ws_act_elems || rgb_elems > g->ws_rgb_elems) {
+        GL_HIP(hipStreamSynchronize(ctx->stream));
+        if (want < g->ws_imgs) want = g->ws_imgs;
+        if (act < g->ws_act_elems) act = g->ws_act_elems;
+        const size_t rgb_alloc = rgb_elems > g->ws_rgb_elems ? rgb_elems : g->ws_rgb_elems;
+        (void)hipFree(g->ws_z);
+        for (int k = 0; k < 3; ++k) { (void)hipFree(g->ws_buf[k]); g->ws_buf[k] = nullptr; }
+        for (int k = 0; k < 2; ++k) { (void)hipFree(g->ws_rgb[k]); g->ws_rgb[k] = nullptr; }
+        g->ws_z = nullptr;
+        g->ws_imgs = 0;
+        GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
+        for (int k = 0; k < 3; ++k) GL_HIP(hipMalloc((void **)&g->ws_buf[k], (size_t)want * act * 4));
+        for (int k = 0; k < 2; ++k) GL_HIP(hipMalloc((void **)&g->ws_rgb[k], (size_t)want * rgb_alloc * 4 + 64));
+        g->ws_imgs = want;
+        g->ws_act_elems = act;
+        g->ws_rgb_elems = rgb_alloc;
+    }
+    const int64_t img_elems = (int64_t)nc * R * R;
+    int rc;
+
+    for (int64_t i0 = 0; i0 < n; i0 += g->ws_imgs) {
+        const int64_t m = (n - i0 < g->ws_imgs) ? n - i0 : g->ws_imgs;
+        hipLaunchKernelGGL(pixelnorm_rows_kernel, dim3((unsigned)gl_ceil_div(m, 4)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim, g->z_pad,
+                           g->ws_z);
+        GL_LAUNCH_CHECK();
+        // ConvTranspose2d(z, C, 4, 1, 0) + bias + LeakyReLU : one GEMM to NHWC 4x4xC
+        {
+            GlGatherConv p = {};
+            p.in = g->ws_z; p.positions = m; p.H = 1; p.W = 1; p.Cin = g->z_pad;
+            p.wpack = g->w_init; p.cols = 16 * C; p.cols_pad = cols_pad_of(16 * C); p.ntaps = 1; p.tap_dy[0] = 1; p.tap_dx[0] = 1;
+            p.out = g->ws_buf[0]; p.Ho = 1; p.Wo = 1; p.omul = 1;
+            p.scale = g->ones; p.shift = g->b_init; p.cmod = C; p.act = 2; p.zero = ctx->zero_page;
+            rc = gl_launch_gather_conv(ctx, p, 1);
+            if (rc != GL_OK) return rc;
+        }
+        rc = pg_conv(g, g->ws_buf[0], m, 4, 4, 0, C, g->w_i3, g->b_i3, C, 9, 2, g->ws_buf[1]);
+        if (rc != GL_OK) return rc;
+        rc = pg_pixelnorm(g, g->ws_buf[1], m * 16, C);
+        if (rc != GL_OK) return rc;
+        int cur = 1, prev = 1, hw = 4;
+        for (int s = 0; s < steps; ++s) {
+            hw *= 2;
+            const int b1 = (cur + 1) % 3, b2 = (cur + 2) % 3;
+            rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 1, g->cin[s], g->w_blk[s][0], g->b_blk[s][0], g->cout[s], 9, 2, g->ws_buf[b1]);
+            if (rc == GL_OK) rc = pg_pixelnorm(g, g->ws_buf[b1], m * hw * hw, g->cout[s]);
+            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2]);
+            if (rc == GL_OK) rc = pg_pixelnorm(g, g->ws_buf[b2], m * hw * hw, g->cout[s]);
+            if (rc != GL_OK) return rc;
+            prev = cur;      // input of this block (low resolution): `upscaled` of the reference is its x2 view
+            cur = b2;
+        }
+        // toRGB
+        rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 0, rgb_cin(g, steps), g->w_rgb[steps], g->b_rgb[steps], nc, 1, 0, g->ws_rgb[0]);
+        if (rc != GL_OK) return rc;
+        const float *brgb = nullptr;
+        if (steps > 0 && alpha != 1.0f) {
+            // rgb[steps-1](upscaled): the 1x1 convolution commutes with nearest upsampling, so it runs at half resolution.
+            // With alpha == 1 the term is multiplied by exactly 0 (finite values), so it is skipped.
+            rc = pg_conv(g, g->ws_buf[prev], m, hw / 2, hw / 2, 0, rgb_cin(g, steps - 1), g->w_rgb[steps - 1], g->b_rgb[steps - 1], nc, 1, 0, g->ws_rgb[1]);
+            if (rc != GL_OK) return rc;
+            brgb = g->ws_rgb[1];
+        }
+        {
+            const int64_t tot = m * img_elems;
+            int64_t blocks = gl_ceil_div(tot, 256);
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(pggan_output_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g->ws_rgb[0], brgb, m, R, nc, alpha, steps > 0 ? 1 : 0,
+                               out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr, out_u8_dev ? out_u8_dev + i0 * img_elems : nullptr);
+            GL_LAUNCH_CHECK();
+        }
+    }
+    return GL_OK;
+}
+
+}  // extern "C"

@@ -97,3 +97,34 @@ def vgg16_state_dict(seed=7, bias_std=0.05):
         sd[f"{k}.bias"] = rng.normal(0.0, bias_std, size=v).astype(np.float32)
         cin = v
     return sd
+
+
+PGGAN_FACTORS = [1, 1, 1, 1, 1 / 2, 1 / 4, 1 / 8, 1 / 16, 1 / 32]      # gan_models/pggan/model_torch.py:6
+
+
+def pggan_state_dict(seed=4321, z_dim=512, in_channels=512, img_channels=3, prefix=""):
+    """Random PGGAN generator weights under the reference's key names (gan_models/pggan/model_torch.py:49-69):
+    initial.1.{weight [z,C,4,4], bias}, initial.3.{conv.weight [C,C,3,3], bias}, initial_rgb.{conv.weight, bias},
+    prog_blocks.{i}.conv{1,2}.{conv.weight, bias}, rgb_layers.{j}.{conv.weight, bias} with rgb_layers.0 the SAME
+    tensors as initial_rgb.  WSConv weights ~ N(0,1) as in the reference's init (model_torch.py:17); biases are
+    random instead of zero so that they are exercised."""
+    rng = np.random.default_rng(seed)
+    C = in_channels
+    sd = {}
+
+    def ws(name, cin, cout, k):
+        sd[prefix + name + ".conv.weight"] = rng.normal(0.0, 1.0, size=(cout, cin, k, k)).astype(np.float32)
+        sd[prefix + name + ".bias"] = rng.normal(0.0, 0.1, size=cout).astype(np.float32)
+
+    sd[prefix + "initial.1.weight"] = rng.normal(0.0, 1.0 / np.sqrt(z_dim), size=(z_dim, C, 4, 4)).astype(np.float32)
+    sd[prefix + "initial.1.bias"] = rng.normal(0.0, 0.1, size=C).astype(np.float32)
+    ws("initial.3", C, C, 3)
+    ws("initial_rgb", C, img_channels, 1)
+    sd[prefix + "rgb_layers.0.conv.weight"] = sd[prefix + "initial_rgb.conv.weight"]
+    sd[prefix + "rgb_layers.0.bias"] = sd[prefix + "initial_rgb.bias"]
+    for i in range(len(PGGAN_FACTORS) - 1):
+        cin, cout = int(C * PGGAN_FACTORS[i]), int(C * PGGAN_FACTORS[i + 1])
+        ws(f"prog_blocks.{i}.conv1", cin, cout, 3)
+        ws(f"prog_blocks.{i}.conv2", cout, cout, 3)
+        ws(f"rgb_layers.{i + 1}", cout, img_channels, 1)
+    return sd

@@ -40,6 +40,7 @@ typedef enum gl_status {
 typedef struct gl_ctx gl_ctx;       /* opaque: device + stream + scratch */
 typedef struct gl_dcgan gl_dcgan;   /* opaque: packed DCGAN / WGAN-GP generator */
 typedef struct gl_lpips gl_lpips;   /* opaque: VGG16 + LPIPS v0.1 lin layers */
+typedef struct gl_pggan gl_pggan;   /* opaque: packed progressive-GAN generator */
 
 /* ---------------------------------------------------------------- library / context */
 int gl_abi_version(void);
@@ -147,6 +148,24 @@ int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias_host);   /* gen.4.bias 
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev);
 /* images per internal pass (activations for that many images stay resident); 0 = default */
 int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass);
+
+/* ---------------------------------------------------------------- PGGAN generator */
+/* gan_models/pggan/model_torch.py:49-88 Generator(z_dim, in_channels, img_channels).forward(x, steps, alpha)
+ * (WSConv2d :8-22, PixelNorm :25-31, ConvBlock :33-47).  in_channels must be a multiple of 32 and every block that
+ * is used must keep >= 32 channels (steps <= 6 at in_channels = 512).  Weights are HOST pointers in the
+ * reference's state_dict layouts. */
+int gl_pggan_create(gl_ctx *ctx, int z_dim, int in_channels, int img_channels, gl_pggan **out);
+int gl_pggan_destroy(gl_pggan *g);
+/* initial.1.{weight [z][C][4][4], bias [C]}, initial.3.{conv.weight [C][C][3][3], bias [C]} */
+int gl_pggan_set_initial(gl_pggan *g, const float *convt_w_host, const float *convt_b_host, const float *ws_w_host, const float *ws_b_host);
+/* prog_blocks.{block}.conv1.{conv.weight, bias}, .conv2.{conv.weight, bias}; block 0..7 */
+int gl_pggan_set_block(gl_pggan *g, int block, const float *conv1_w_host, const float *conv1_b_host, const float *conv2_w_host, const float *conv2_b_host);
+/* rgb_layers.{j}.{conv.weight [nc][C_j][1][1], bias [nc]}; j = 0 is initial_rgb */
+int gl_pggan_set_rgb(gl_pggan *g, int j, const float *w_host, const float *b_host);
+int gl_pggan_set_chunk(gl_pggan *g, int64_t images_per_pass);
+/* z_dev [n][z_dim] -> [n][nc][R][R], R = 4 * 2^steps.  out_f32_dev: what forward() returns; out_u8_dev: the bytes the
+ * generate branch writes (gan_models/pggan/train.py:238-246: x*0.5+0.5, ToPILImage).  Either may be NULL. */
+int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, float alpha, float *out_f32_dev, uint8_t *out_u8_dev);
 
 /* ---------------------------------------------------------------- LPIPS (0.2 * LPIPS + L2, the reference's fbb distance) */
 /* PerceptualLoss(model='net-lin', net='vgg') (attack_models/lpips_pytorch/__init__.py:9-32) -> PNetLin

@@ -229,6 +229,34 @@ def make_lpips(fbb):
         print(name, "idx", i, "dist", np.round(d, 4), "lpips range", lp.min(), lp.max())
 
 
+PGGAN_CASES = [  # (z_dim, in_channels, steps, alpha)
+    (64, 64, 0, 1.0), (64, 64, 1, 1.0), (64, 64, 2, 0.5), (64, 64, 4, 1.0), (64, 64, 4, 0.3), (96, 128, 3, 1.0),
+]
+
+
+def make_pggan(pg):
+    """gan_models/pggan/model_torch.py:49-88 Generator.forward(x, steps, alpha) and :207-216 stackGenerators"""
+    out = {}
+    for ci, (z_dim, C, steps, alpha) in enumerate(PGGAN_CASES):
+        sd_np = synth.pggan_state_dict(4321 + C, z_dim, C)
+        g = pg.Generator(z_dim, C, 3)
+        print("pggan keys match:", g.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True))
+        g.eval()
+        z = synth.latent(3, 4, z_dim)
+        with torch.no_grad():
+            out["case%d" % ci] = g(torch.from_numpy(z), steps, alpha).numpy()
+        print("pggan case", ci, out["case%d" % ci].shape, float(out["case%d" % ci].std()))
+    st = pg.stackGenerators(64, 64, 3, 2)
+    sd = {}
+    for gi in range(2):
+        sd.update({k: torch.from_numpy(v) for k, v in synth.pggan_state_dict(100 + gi, 64, 64, prefix="gen.%d." % gi).items()})
+    st.load_state_dict(sd, strict=True)
+    st.eval()
+    with torch.no_grad():
+        out["stack_g1"] = st(torch.from_numpy(synth.latent(3, 4, 64)), 2, 1.0, 1).numpy()
+    np.savez(os.path.join(HERE, "pggan_gen.npz"), cases=np.array(PGGAN_CASES, np.float64), **out)
+
+
 def make_png(ref_utils):
     """attack_models/utils.py:43-84: sorted path order + read_image (incl. the PIL resize branch)."""
     import PIL.Image
@@ -250,6 +278,9 @@ def make_png(ref_utils):
 
 if __name__ == "__main__":
     fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
+    if "--pggan-only" in sys.argv:
+        make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
+        sys.exit(0)
     if "--lpips-only" in sys.argv:
         make_lpips(fbb)
         sys.exit(0)
@@ -264,3 +295,4 @@ if __name__ == "__main__":
     dc = _refimport.load("gan_models/dcgan/model_torch.py", "ref_dcgan_model")
     wg = _refimport.load("gan_models/wgangp/model.py", "ref_wgangp_model")
     make_dcgan(dc, wg)
+    make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))

@@ -1,0 +1,85 @@
+"""GPU parity tests of the PGGAN generator (fp32 MFMA convolutions, fused nearest upsampling) against the
+reference Generator's outputs (tests/golden/pggan_gen.npz) and the fp64 oracle.  Tolerance 5e-5 on
+outputs in (-1,1) (north_star: 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ATOL = 5e-5
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import ganleaks_amd
+    return ganleaks_amd
+
+
+def test_generator_matches_reference(gl, synth, golden_dir):
+    from ganleaks_amd.gan_models.pggan.model_torch import Generator, stackGenerators
+    g = np.load(os.path.join(golden_dir, "pggan_gen.npz"))
+    gens = {}
+    for ci, (z_dim, C, steps, alpha) in enumerate(g["cases"]):
+        z_dim, C, steps = int(z_dim), int(C), int(steps)
+        if (z_dim, C) not in gens:
+            gen = Generator(z_dim, C, 3)
+            assert "matched" in gen.load_state_dict(synth.pggan_state_dict(4321 + C, z_dim, C))
+            gens[(z_dim, C)] = gen
+        out = gens[(z_dim, C)](synth.latent(3, 4, z_dim), steps, float(alpha))
+        ref = g["case%d" % ci]
+        assert out.shape == ref.shape and out.dtype == np.float32
+        err = np.abs(out - ref).max()
+        assert err < ATOL, (ci, err)
+    st = stackGenerators(64, 64, 3, 2)
+    sd = {}
+    for gi in range(2):
+        sd.update(synth.pggan_state_dict(100 + gi, 64, 64, prefix="gen.%d." % gi))
+    st.load_state_dict(sd)
+    assert np.abs(st(synth.latent(3, 4, 64), 2, 1.0, 1) - g["stack_g1"]).max() < ATOL
+
+
+def test_codes_chunks_and_oracle(gl, synth, oracle):
+    import pggan_oracle
+    from ganleaks_amd.gan_models.pggan.model_torch import Generator
+    sd = synth.pggan_state_dict(77, 128, 128)
+    gen = Generator(128, 128, 3)
+    gen.load_state_dict(sd)
+    z = synth.latent(9, 21, 128)
+    f32, u8 = gen.forward_device(z, 3, 1.0, True, True)
+    f, u = f32.numpy(), u8.numpy()
+    assert f.shape == (21, 3, 32, 32)
+    assert np.array_equal(u, oracle.quantize_to_u8(f, "half"))           # pggan/train.py:238 mapping
+    ref = pggan_oracle.pggan_forward(sd, z[:5], 3, 1.0)
+    assert np.abs(f[:5] - ref).max() < ATOL
+    gen2 = Generator(128, 128, 3)
+    gen2.load_state_dict(sd)
+    gen2.set_chunk(8)                                                     # 21 = 8 + 8 + 5
+    assert np.array_equal(gen2(z, 3, 1.0), f)
+    # fade-in branch and depth change on the same object
+    ref = pggan_oracle.pggan_forward(sd, z[:3], 2, 0.25)
+    assert np.abs(gen(z[:3], 2, 0.25) - ref).max() < ATOL
+    ref = pggan_oracle.pggan_forward(sd, z[:2], 0, 1.0)
+    assert np.abs(gen(z[:2], 0, 1.0) - ref).max() < ATOL
+    with pytest.raises(gl.GanLeaksError):
+        gen(z[:2], 3 + 2, 1.0)          # block 4 of a 128-channel model has 16 channels: refused, not wrong
+    with pytest.raises(KeyError):
+        bad = dict(sd)
+        del bad["prog_blocks.1.conv2.bias"]
+        Generator(128, 128, 3).load_state_dict(bad)
+
+
+def test_pggan_bank_attack(gl, synth):
+    """generator-direct bank -> L2 1-NN, as the fbb attack would use it"""
+    import c_oracle
+    from ganleaks_amd.gan_models.pggan.model_torch import Generator
+    gen = Generator(64, 64, 3)
+    gen.load_state_dict(synth.pggan_state_dict(4321 + 64, 64, 64))
+    bank = gen.generate_u8(synth.latent(11, 200, 64), steps=4, alpha=1.0)
+    hb = bank.numpy()
+    q = synth.perturb_u8(2, hb[[7, 150, 199]], 5.0)
+    d, i = gl.attack(q, bank, batch_size=64)
+    od, oi, _ = c_oracle.knn_l2_u8(hb, q, 64)
+    assert np.array_equal(i, oi) and np.array_equal(d, od) and i[0] == 7 and i[1] == 150 and i[2] != 199
