@@ -64,7 +64,7 @@ def test_codes_chunks_and_oracle(gl, synth, oracle):
     ref = pggan_oracle.pggan_forward(sd, z[:2], 0, 1.0)
     assert np.abs(gen(z[:2], 0, 1.0) - ref).max() < ATOL
     with pytest.raises(gl.GanLeaksError):
-        gen(z[:2], 3 + 2, 1.0)          # block 4 of a 128-channel model has 16 channels: refused, not wrong
+        gen(z[:2], 6, 1.0)              # block 5 of a 128-channel model has 32 -> 16 channels: refused, not wrong
     with pytest.raises(KeyError):
         bad = dict(sd)
         del bad["prog_blocks.1.conv2.bias"]
