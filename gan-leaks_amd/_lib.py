@@ -81,6 +81,12 @@ SIGNATURES = {
     "gl_pggan_set_rgb": (_i, [_p, _i, _p, _p]),
     "gl_pggan_set_chunk": (_i, [_p, _i64]),
     "gl_pggan_forward": (_i, [_p, _p, _i64, _i, ctypes.c_float, _p, _p]),
+    "gl_medgan_create": (_i, [_p, _i, _i, _i, _i, _pp]),
+    "gl_medgan_destroy": (_i, [_p]),
+    "gl_medgan_set_gen_block": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, ctypes.c_float]),
+    "gl_medgan_set_decoder": (_i, [_p, _p, _p]),
+    "gl_medgan_generate": (_i, [_p, _p, _i64, _p]),
+    "gl_medgan_decode": (_i, [_p, _p, _i64, _p, _p]),
     "gl_lpips_create": (_i, [_p, _pp]),
     "gl_lpips_destroy": (_i, [_p]),
     "gl_lpips_set_conv": (_i, [_p, _i, _p, _p]),

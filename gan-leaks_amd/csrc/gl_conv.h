@@ -24,10 +24,12 @@ struct GlGatherConv {
     // planar != 0: write column-major out[c * ld_planar + position] instead (single phase, identity position map)
     int planar;
     int64_t ld_planar;
-    // epilogue: v = acc * scale[c % cmod] + shift[c % cmod]; act 0 none, 1 ReLU, 2 LeakyReLU(0.2)
+    // epilogue: v = act(acc * scale[c % cmod] + shift[c % cmod]) (+ residual[same index as out], row-major only);
+    // act 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh, 4 sigmoid
     const float *scale, *shift;
     int cmod;
     int act;
+    const float *residual;
     const float *zero;          // >= 16 B of zeros (source of out-of-image taps)
 };
 

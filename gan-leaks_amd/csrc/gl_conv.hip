@@ -182,8 +182,18 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     // only the last, ragged position tile takes the checked variant.
     const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
     const float neg_slope = p.act == 2 ? 0.2f : 1.0f;     // act 2: LeakyReLU(0.2) = max(v, 0.2 v)
-    auto store_tile = [&](auto checked) {
+    auto store_tile = [&](auto checked, auto slow_act) {
         constexpr bool CHECK = decltype(checked)::value;
+        constexpr bool SLOW = decltype(slow_act)::value;     // act 3 (tanh) / 4 (sigmoid) and/or a residual input
+        auto finish = [&](float v, int64_t idx) {
+            v = fmaxf(fmaxf(v, v * neg_slope), relu_floor);
+            if (SLOW) {
+                if (p.act == 3) v = tanhf(v);
+                else if (p.act == 4) v = 1.0f / (1.0f + __expf(-v));
+                if (p.residual) v += p.residual[idx];
+            }
+            return v;
+        };
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int c = c0 + (wn * TN + j) * 32 + frow;
@@ -198,11 +208,12 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int o = o32[i][4 * g];
+                        const int64_t base = (int64_t)c * p.ld_planar + o;
                         float4 v;
-                        v.x = fmaf(acc[i][j][4 * g + 0], sc, sh); v.x = fmaxf(fmaxf(v.x, v.x * neg_slope), relu_floor);
-                        v.y = fmaf(acc[i][j][4 * g + 1], sc, sh); v.y = fmaxf(fmaxf(v.y, v.y * neg_slope), relu_floor);
-                        v.z = fmaf(acc[i][j][4 * g + 2], sc, sh); v.z = fmaxf(fmaxf(v.z, v.z * neg_slope), relu_floor);
-                        v.w = fmaf(acc[i][j][4 * g + 3], sc, sh); v.w = fmaxf(fmaxf(v.w, v.w * neg_slope), relu_floor);
+                        v.x = finish(fmaf(acc[i][j][4 * g + 0], sc, sh), base + 0);
+                        v.y = finish(fmaf(acc[i][j][4 * g + 1], sc, sh), base + 1);
+                        v.z = finish(fmaf(acc[i][j][4 * g + 2], sc, sh), base + 2);
+                        v.w = finish(fmaf(acc[i][j][4 * g + 3], sc, sh), base + 3);
                         if (c_ok && (!CHECK || o >= 0)) *reinterpret_cast<float4 *>(colp + o) = v;
                     }
             } else {
@@ -212,15 +223,23 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = o32[i][r];
-                        float v = fmaf(acc[i][j][r], sc, sh);
-                        v = fmaxf(fmaxf(v, v * neg_slope), relu_floor);
-                        if (c_ok && (!CHECK || o >= 0)) colp[(int64_t)o * p.cols] = v;
+                        if (c_ok && (!CHECK || o >= 0)) {
+                            const int64_t idx = (int64_t)o * p.cols + c;
+                            colp[(int64_t)o * p.cols] = finish(fmaf(acc[i][j][r], sc, sh), idx);
+                        }
                     }
             }
         }
     };
-    if (m0 + BM <= p.positions) store_tile(std::false_type{});
-    else store_tile(std::true_type{});
+    const bool slow = p.act >= 3 || p.residual != nullptr;
+    const bool full = m0 + BM <= p.positions;
+    if (slow) {
+        if (full) store_tile(std::false_type{}, std::true_type{});
+        else store_tile(std::true_type{}, std::true_type{});
+    } else {
+        if (full) store_tile(std::false_type{}, std::false_type{});
+        else store_tile(std::true_type{}, std::false_type{});
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,6 +338,7 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
     GL_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.wpack) & 15) == 0, "gather_conv: unaligned operand");
     GL_REQUIRE((p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31) && p.positions < (1ll << 31),
                "gather_conv: more than 2^31 positions in one launch");
+    GL_REQUIRE(p.act >= 0 && p.act <= 4 && !(p.planar && p.residual), "gather_conv: bad activation code / residual with planar output");
     GL_REQUIRE(p.up == 0 || (p.up == 1 && p.H % 2 == 0 && p.W % 2 == 0), "gather_conv: up must be 0 or 1 (even H, W)");
     if (p.planar)
         GL_REQUIRE(phases == 1 && p.omul == 1 && p.Ho == p.H && p.Wo == p.W && p.positions % 4 == 0 && p.ld_planar % 4 == 0 &&

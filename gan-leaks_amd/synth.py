@@ -128,3 +128,22 @@ def pggan_state_dict(seed=4321, z_dim=512, in_channels=512, img_channels=3, pref
         ws(f"prog_blocks.{i}.conv2", cout, cout, 3)
         ws(f"rgb_layers.{i + 1}", cout, img_channels, 1)
     return sd
+
+
+def medgan_state_dicts(seed=555, input_size=1071):
+    """(generator sd, autoencoder sd) under the reference's key names (gan_models/medgan/model.py)."""
+    rng = np.random.default_rng(seed)
+    g = {}
+    for name in ("gen_block1", "gen_block2"):
+        g[f"{name}.0.weight"] = rng.normal(0.0, 1.0 / np.sqrt(128), size=(128, 128)).astype(np.float32)
+        g[f"{name}.0.bias"] = rng.normal(0.0, 0.1, size=128).astype(np.float32)
+        g[f"{name}.1.weight"] = rng.normal(1.0, 0.1, size=128).astype(np.float32)
+        g[f"{name}.1.bias"] = rng.normal(0.0, 0.1, size=128).astype(np.float32)
+        g[f"{name}.1.running_mean"] = rng.normal(0.0, 0.1, size=128).astype(np.float32)
+        g[f"{name}.1.running_var"] = rng.uniform(0.5, 1.5, size=128).astype(np.float32)
+        g[f"{name}.1.num_batches_tracked"] = np.array(1, np.int64)
+    a = {"encoder.0.weight": rng.normal(0.0, 0.05, size=(128, input_size)).astype(np.float32),
+         "encoder.0.bias": rng.normal(0.0, 0.1, size=128).astype(np.float32),
+         "decoder.0.weight": rng.normal(0.0, 1.0 / np.sqrt(128), size=(input_size, 128)).astype(np.float32),
+         "decoder.0.bias": rng.normal(0.0, 0.3, size=input_size).astype(np.float32)}
+    return g, a

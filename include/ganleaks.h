@@ -41,6 +41,7 @@ typedef struct gl_ctx gl_ctx;       /* opaque: device + stream + scratch */
 typedef struct gl_dcgan gl_dcgan;   /* opaque: packed DCGAN / WGAN-GP generator */
 typedef struct gl_lpips gl_lpips;   /* opaque: VGG16 + LPIPS v0.1 lin layers */
 typedef struct gl_pggan gl_pggan;   /* opaque: packed progressive-GAN generator */
+typedef struct gl_medgan gl_medgan; /* opaque: medGAN residual-MLP generator + autoencoder decoder */
 
 /* ---------------------------------------------------------------- library / context */
 int gl_abi_version(void);
@@ -166,6 +167,21 @@ int gl_pggan_set_chunk(gl_pggan *g, int64_t images_per_pass);
 /* z_dev [n][z_dim] -> [n][nc][R][R], R = 4 * 2^steps.  out_f32_dev: what forward() returns; out_u8_dev: the bytes the
  * generate branch writes (gan_models/pggan/train.py:238-246: x*0.5+0.5, ToPILImage).  Either may be NULL. */
 int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, float alpha, float *out_f32_dev, uint8_t *out_u8_dev);
+
+/* ---------------------------------------------------------------- medGAN (tabular) */
+/* gan_models/medgan/model.py:44-73 Generator(z_dim, hidden_size) and :13-41 Autoencoder(input_size, hidden_size, binary).decode,
+ * used together at gan_models/medgan/train.py:306-312.  z_dim == hidden_size == 128 (forced by the residual adds). */
+int gl_medgan_create(gl_ctx *ctx, int z_dim, int hidden_size, int input_size, int binary, gl_medgan **out);
+int gl_medgan_destroy(gl_medgan *g);
+/* block 0/1 = gen_block{1,2}: .0.{weight [128][in], bias}, .1.{weight, bias, running_mean, running_var}; eps = 1e-3 (model.py:52,57) */
+int gl_medgan_set_gen_block(gl_medgan *g, int block, const float *lin_w_host, const float *lin_b_host, const float *gamma_host, const float *beta_host,
+                            const float *mean_host, const float *var_host, float eps);
+/* decoder.0.{weight [input_size][hidden], bias [input_size]} */
+int gl_medgan_set_decoder(gl_medgan *g, const float *w_host, const float *b_host);
+/* Generator.forward: z_dev [n][128] -> hidden_out_dev [n][128] */
+int gl_medgan_generate(gl_medgan *g, const float *z_dev, int64_t n, float *hidden_out_dev);
+/* Autoencoder.decode: hidden_dev [n][128] -> decoded_dev [n][input_size]; binary_dev (may be NULL) = (decoded >= 0.5), train.py:311-312 */
+int gl_medgan_decode(gl_medgan *g, const float *hidden_dev, int64_t n, float *decoded_dev, float *binary_dev);
 
 /* ---------------------------------------------------------------- LPIPS (0.2 * LPIPS + L2, the reference's fbb distance) */
 /* PerceptualLoss(model='net-lin', net='vgg') (attack_models/lpips_pytorch/__init__.py:9-32) -> PNetLin

@@ -257,6 +257,27 @@ def make_pggan(pg):
     np.savez(os.path.join(HERE, "pggan_gen.npz"), cases=np.array(PGGAN_CASES, np.float64), **out)
 
 
+def make_medgan(mg):
+    """gan_models/medgan/model.py:44-73 Generator, :13-41 Autoencoder.decode, chained as medgan/train.py:306-312"""
+    gsd, asd = synth.medgan_state_dicts(555, 1071)
+    z = np.random.default_rng(8).standard_normal((37, 128)).astype(np.float32)
+    gen = mg.Generator(128, 128)
+    print("medgan gen:", gen.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in gsd.items()}, strict=True))
+    gen.eval()
+    out = {}
+    for binary in (True, False):
+        ae = mg.Autoencoder(1071, 128, binary=binary)
+        ae.load_state_dict({k: torch.from_numpy(v) for k, v in asd.items()}, strict=True)
+        ae.eval()
+        with torch.no_grad():
+            h = gen(torch.from_numpy(z))
+            dec = ae.decoder(h)
+        out["hidden"] = h.numpy()
+        out["decoded_binary%d" % int(binary)] = dec.numpy()
+    np.savez(os.path.join(HERE, "medgan_gen.npz"), **out)
+    print("medgan hidden std", out["hidden"].std(), "decoded mean", out["decoded_binary1"].mean())
+
+
 def make_png(ref_utils):
     """attack_models/utils.py:43-84: sorted path order + read_image (incl. the PIL resize branch)."""
     import PIL.Image
@@ -280,6 +301,10 @@ if __name__ == "__main__":
     fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
     if "--pggan-only" in sys.argv:
         make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
+    make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
+        sys.exit(0)
+    if "--medgan-only" in sys.argv:
+        make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
         sys.exit(0)
     if "--lpips-only" in sys.argv:
         make_lpips(fbb)
@@ -296,3 +321,4 @@ if __name__ == "__main__":
     wg = _refimport.load("gan_models/wgangp/model.py", "ref_wgangp_model")
     make_dcgan(dc, wg)
     make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
+    make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
