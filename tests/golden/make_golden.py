@@ -301,7 +301,6 @@ if __name__ == "__main__":
     fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
     if "--pggan-only" in sys.argv:
         make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
-    make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
         sys.exit(0)
     if "--medgan-only" in sys.argv:
         make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
