@@ -70,6 +70,21 @@ __device__ __forceinline__ unsigned gl_xcd_remap(unsigned bid, unsigned nwg)
     return start + (bid >> 3);
 }
 
+// pairwise kernels: logical block id -> (bank tile nt, query tile qt) in strips of STRIP bank tiles with the bank
+// tile varying fastest.  The ~64 blocks an XCD runs at once then cover ~8 bank tiles x 8 query tiles, so each
+// K slice needs 16 operand panels from beyond L2 instead of 65 (1 bank + 64 query panels) -- measured with
+// FETCH_SIZE: 107 GB -> see profiles/.
+__device__ __forceinline__ void gl_strip_order(unsigned id, int q_tiles, int n_tiles, int &qt, int &nt)
+{
+    constexpr int STRIP = 8;
+    const unsigned per_strip = (unsigned)STRIP * (unsigned)q_tiles;
+    const int strip = (int)(id / per_strip);
+    const unsigned r = id % per_strip;
+    const int width = n_tiles - strip * STRIP < STRIP ? n_tiles - strip * STRIP : STRIP;   // last strip may be narrower
+    nt = strip * STRIP + (int)(r % (unsigned)width);
+    qt = (int)(r / (unsigned)width);
+}
+
 typedef __attribute__((address_space(1))) const void *gl_gptr;
 typedef __attribute__((address_space(3))) void *gl_lptr;
 

@@ -53,8 +53,8 @@ l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ ba
 
     const unsigned nwg = (unsigned)q_tiles * (unsigned)n_tiles;
     const unsigned id = gl_xcd_remap(blockIdx.x, nwg);
-    const int qt = (int)(id % (unsigned)q_tiles);     // neighbours on an XCD share the bank panel
-    const int nt = (int)(id / (unsigned)q_tiles);
+    int qt, nt;
+    gl_strip_order(id, q_tiles, n_tiles, qt, nt);     // co-resident blocks of an XCD: ~8 bank tiles x 8 query tiles
     const int64_t n0 = (int64_t)nt * TILE_N, q0 = (int64_t)qt * TILE_Q;
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -192,7 +192,8 @@ feat_knn_f32_kernel(const float *__restrict__ bank, const float *__restrict__ ba
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
-    const int qt = (int)(id % (unsigned)q_tiles), nt = (int)(id / (unsigned)q_tiles);
+    int qt, nt;
+    gl_strip_order(id, q_tiles, n_tiles, qt, nt);
     const int64_t n0 = (int64_t)nt * FT, q0 = (int64_t)qt * FT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
