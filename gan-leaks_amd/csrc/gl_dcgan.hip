@@ -20,6 +20,10 @@ struct gl_dcgan {
     float *ws_z, *ws_a[4];     // z padded; outputs of layers 0..3
     float *ws_p;               // scatter-form output of layer 4: [img][H*W][16 taps * nc]
     float *ident_scale, *ident_shift;   // epilogue constants (1, 0) for the layer-4 GEMM
+    // optional self-attention on the output of layer 2 (VAEGAN: gan_models/vaegan/ops.py:86-120)
+    bool have_att;
+    float *att_wq, *att_bq, *att_wk, *att_bk, *att_wv, *att_bv, att_gamma;
+    float *ws_att;
 };
 
 namespace {
@@ -46,6 +50,72 @@ int upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
     return GL_OK;
 }
 
+
+// Self-attention (SAGAN style) over the T = 256 positions of a 16 x 16 map, per image
+// (gan_models/vaegan/ops.py:101-120):
+//   q = Wq x + bq, k = Wk x + bk  (C/8 channels), energy_ij = q_i . k_j, att = softmax_j(energy),
+//   out_i = sum_j att_ij (Wv x_j + bv) = Wv (sum_j att_ij x_j) + bv   (rows of att sum to 1),  y = gamma * out + x
+// One workgroup per image, one thread per position i.  Everything indexed by j or by a weight is wave-uniform
+// (scalar loads / LDS broadcast); per thread: q_i (C/8 regs), the running sum over j (C regs).
+template <int C>
+__global__ void __launch_bounds__(256) self_attention_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ wq,
+                                                             const float *__restrict__ bq, const float *__restrict__ wk, const float *__restrict__ bk,
+                                                             const float *__restrict__ wv, const float *__restrict__ bv, float gamma)
+{
+    constexpr int DK = C / 8, T = 256;
+    __shared__ float ks[T][DK];
+    const int i = threadIdx.x;
+    const float *ximg = x + (int64_t)blockIdx.x * T * C;
+    const float *xi = ximg + (int64_t)i * C;
+    float q[DK], kk[DK];
+#pragma unroll
+    for (int d = 0; d < DK; ++d) { q[d] = bq[d]; kk[d] = bk[d]; }
+    for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(xi + c);
+#pragma unroll
+        for (int d = 0; d < DK; ++d) {
+            q[d] = fmaf(wq[d * C + c + 0], v.x, q[d]); q[d] = fmaf(wq[d * C + c + 1], v.y, q[d]);
+            q[d] = fmaf(wq[d * C + c + 2], v.z, q[d]); q[d] = fmaf(wq[d * C + c + 3], v.w, q[d]);
+            kk[d] = fmaf(wk[d * C + c + 0], v.x, kk[d]); kk[d] = fmaf(wk[d * C + c + 1], v.y, kk[d]);
+            kk[d] = fmaf(wk[d * C + c + 2], v.z, kk[d]); kk[d] = fmaf(wk[d * C + c + 3], v.w, kk[d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DK; ++d) ks[i][d] = kk[d];
+    __syncthreads();
+    float m = -__builtin_inff();
+    for (int j = 0; j < T; ++j) {
+        float e = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) e = fmaf(q[d], ks[j][d], e);
+        m = fmaxf(m, e);
+    }
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+    float ssum = 0.0f;
+    for (int j = 0; j < T; ++j) {
+        float e = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DK; ++d) e = fmaf(q[d], ks[j][d], e);
+        const float pj = __expf(e - m);
+        ssum += pj;
+        const float *xj = ximg + (int64_t)j * C;       // wave-uniform address
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fmaf(pj, xj[c], acc[c]);
+    }
+    const float inv = 1.0f / ssum;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] *= inv;
+    float *yi = y + ((int64_t)blockIdx.x * T + i) * C;
+    for (int co = 0; co < C; ++co) {
+        float o = bv[co];
+#pragma unroll
+        for (int c = 0; c < C; ++c) o = fmaf(wv[co * C + c], acc[c], o);
+        yi[co] = fmaf(gamma, o, xi[co]);
+    }
+}
+
 int ensure_workspace(gl_dcgan *g, int64_t n)
 {
     int64_t want = g->chunk > 0 ? g->chunk : 4096;
@@ -57,6 +127,8 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
     for (int l = 0; l < 4; ++l) { (void)hipFree(g->ws_a[l]); g->ws_a[l] = nullptr; }
     (void)hipFree(g->ws_p);
     g->ws_p = nullptr;
+    (void)hipFree(g->ws_att);
+    g->ws_att = nullptr;
     g->ws_chunk = 0;
     GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
     int hw = 16;
@@ -65,6 +137,7 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
         hw *= 4;
     }
     GL_HIP(hipMalloc((void **)&g->ws_p, (size_t)want * 32 * 32 * 16 * g->nc * 4));
+    GL_HIP(hipMalloc((void **)&g->ws_att, (size_t)want * 256 * g->cout[2] * 4));
     g->ws_chunk = want;
     return GL_OK;
 }
@@ -94,6 +167,10 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->ws_chunk = 0;
     g->ws_z = nullptr;
     g->ws_p = nullptr;
+    g->have_att = false;
+    g->att_wq = g->att_bq = g->att_wk = g->att_bk = g->att_wv = g->att_bv = nullptr;
+    g->att_gamma = 0.0f;
+    g->ws_att = nullptr;
     g->ident_scale = g->ident_shift = nullptr;
     {
         std::vector<float> one(16 * channels_img, 1.0f), zero(16 * channels_img, 0.0f);
@@ -114,6 +191,8 @@ int gl_dcgan_destroy(gl_dcgan *g)
     (void)hipFree(g->bias_out);
     (void)hipFree(g->ws_z);
     (void)hipFree(g->ws_p);
+    (void)hipFree(g->ws_att);
+    (void)hipFree(g->att_wq); (void)hipFree(g->att_bq); (void)hipFree(g->att_wk); (void)hipFree(g->att_bk); (void)hipFree(g->att_wv); (void)hipFree(g->att_bv);
     (void)hipFree(g->ident_scale);
     (void)hipFree(g->ident_shift);
     delete g;
@@ -199,6 +278,38 @@ int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias)
     return GL_OK;
 }
 
+/* epilogue of layer 0..3 set directly: y = conv(x) * scale[c] + shift[c], then ReLU.  Used when the caller folds more than
+ * BatchNorm into it (VAEGAN: 1/sigma of the spectral norm and the ConvTranspose bias, gan_models/vaegan/train.py:112-135). */
+int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale, const float *shift)
+{
+    GL_REQUIRE(g && scale && shift && layer >= 0 && layer < 4, "gl_dcgan_set_affine: bad argument");
+    const int c = g->cout[layer];
+    int rc = upload(g->ctx, &g->scale[layer], std::vector<float>(scale, scale + c));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->shift[layer], std::vector<float>(shift, shift + c));
+    if (rc != GL_OK) return rc;
+    g->have_bn[layer] = true;
+    return GL_OK;
+}
+
+/* SelfAttention(in_dim = C2) on the output of layer 2 (16 x 16 x C2, C2 = features_g * 4): query/key conv weights [C2/8][C2],
+ * value conv weight [C2][C2] (1x1 convs), biases, gamma.  gan_models/vaegan/ops.py:86-120. */
+int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const float *wk, const float *bk, const float *wv, const float *bv, float gamma)
+{
+    GL_REQUIRE(g && wq && bq && wk && bk && wv && bv, "gl_dcgan_set_attention: NULL argument");
+    const int C = g->cout[2], DK = C / 8;
+    GL_REQUIRE(C == 64 || C == 128, "gl_dcgan_set_attention: attention width %d unsupported (64 or 128)", C);
+    int rc = upload(g->ctx, &g->att_wq, std::vector<float>(wq, wq + (size_t)DK * C));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bq, std::vector<float>(bq, bq + DK));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_wk, std::vector<float>(wk, wk + (size_t)DK * C));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bk, std::vector<float>(bk, bk + DK));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_wv, std::vector<float>(wv, wv + (size_t)C * C));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bv, std::vector<float>(bv, bv + C));
+    if (rc != GL_OK) return rc;
+    g->att_gamma = gamma;
+    g->have_att = true;
+    return GL_OK;
+}
+
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev)
 {
     GL_REQUIRE(g && n >= 0, "gl_dcgan_forward: bad argument");
@@ -238,7 +349,8 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
         int hw = 4;
         for (int l = 1; l < 4; ++l) {
             GlGatherConv p = {};
-            p.in = g->ws_a[l - 1]; p.positions = m * hw * hw; p.H = hw; p.W = hw; p.Cin = g->cin[l];
+            p.in = (l == 3 && g->have_att) ? g->ws_att : g->ws_a[l - 1];
+            p.positions = m * hw * hw; p.H = hw; p.W = hw; p.Cin = g->cin[l];
             p.wpack = g->wpack[l]; p.cols = g->cout[l]; p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128; p.ntaps = 4;
             for (int py = 0; py < 2; ++py)
                 for (int px = 0; px < 2; ++px) {
@@ -257,6 +369,16 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
             rc = gl_launch_gather_conv(ctx, p, 4);
             if (rc != GL_OK) return rc;
             hw *= 2;
+            if (l == 2 && g->have_att) {
+                GL_REQUIRE(hw == 16, "gl_dcgan_forward: attention expects a 16 x 16 map");
+                if (g->cout[2] == 128)
+                    hipLaunchKernelGGL(self_attention_kernel<128>, dim3((unsigned)m), dim3(256), 0, ctx->stream, g->ws_a[2], g->ws_att, g->att_wq, g->att_bq,
+                                       g->att_wk, g->att_bk, g->att_wv, g->att_bv, g->att_gamma);
+                else
+                    hipLaunchKernelGGL(self_attention_kernel<64>, dim3((unsigned)m), dim3(256), 0, ctx->stream, g->ws_a[2], g->ws_att, g->att_wq, g->att_bq,
+                                       g->att_wk, g->att_bk, g->att_wv, g->att_bv, g->att_gamma);
+                GL_LAUNCH_CHECK();
+            }
         }
         // layer 4: ConvT k4 s2 p1 -> 3 channels: scatter-form GEMM (48 columns) on the matrix cores,
         // then col2im + bias + tanh (+ quantise)

@@ -147,3 +147,40 @@ def medgan_state_dicts(seed=555, input_size=1071):
          "decoder.0.weight": rng.normal(0.0, 1.0 / np.sqrt(128), size=(input_size, 128)).astype(np.float32),
          "decoder.0.bias": rng.normal(0.0, 0.3, size=input_size).astype(np.float32)}
     return g, a
+
+
+def vaegan_state_dict(seed=777, z_dim=100, d=64):
+    """Random VAEGAN generator weights under the reference's key names (gan_models/vaegan/train.py:109-123 with
+    SpectralNorm's weight_bar / weight_u / weight_v, ops.py:56-71).  gamma is non-zero so attention is exercised."""
+    rng = np.random.default_rng(seed)
+    ch = [z_dim, 8 * d, 4 * d, 2 * d, d]
+    sd = {}
+    for l in range(4):
+        name = "deconv%d" % (l + 1)
+        cin, cout = ch[l], ch[l + 1]
+        taps = 16 if l == 0 else 4
+        sd[name + ".module.weight_bar"] = rng.normal(0.0, np.sqrt(2.0 / (cin * taps)), size=(cin, cout, 4, 4)).astype(np.float32)
+        sd[name + ".module.bias"] = rng.normal(0.0, 0.05, size=cout).astype(np.float32)
+        u = rng.normal(0.0, 1.0, size=cin)
+        w2 = sd[name + ".module.weight_bar"].reshape(cin, -1).astype(np.float64)
+        for _ in range(8):                      # a partly converged power iteration, like a trained checkpoint
+            v = w2.T @ u
+            v /= np.linalg.norm(v) + 1e-12
+            u = w2 @ v
+            u /= np.linalg.norm(u) + 1e-12
+        sd[name + ".module.weight_u"] = u.astype(np.float32)
+        sd[name + ".module.weight_v"] = v.astype(np.float32)
+        # spectral normalisation divides by sigma ~ the largest singular value: BatchNorm statistics sized accordingly
+        sd[name + "_bn.weight"] = rng.normal(1.0, 0.1, size=cout).astype(np.float32)
+        sd[name + "_bn.bias"] = rng.normal(0.0, 0.1, size=cout).astype(np.float32)
+        sd[name + "_bn.running_mean"] = rng.normal(0.0, 0.02, size=cout).astype(np.float32)
+        sd[name + "_bn.running_var"] = rng.uniform(0.05, 0.15, size=cout).astype(np.float32)
+        sd[name + "_bn.num_batches_tracked"] = np.array(1, np.int64)
+    sd["deconv5.weight"] = rng.normal(0.0, 0.6 * np.sqrt(1.0 / (d * 4)), size=(d, 3, 4, 4)).astype(np.float32)
+    sd["deconv5.bias"] = rng.normal(0.0, 0.1, size=3).astype(np.float32)
+    C = 2 * d
+    for n, co in (("query", C // 8), ("key", C // 8), ("value", C)):
+        sd["sa1.%s_conv.weight" % n] = rng.normal(0.0, 1.0 / np.sqrt(C), size=(co, C, 1, 1)).astype(np.float32)
+        sd["sa1.%s_conv.bias" % n] = rng.normal(0.0, 0.1, size=co).astype(np.float32)
+    sd["sa1.gamma"] = np.array([0.7], np.float32)
+    return sd

@@ -149,6 +149,12 @@ int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias_host);   /* gen.4.bias 
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev);
 /* images per internal pass (activations for that many images stay resident); 0 = default */
 int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass);
+/* VAEGAN generator (gan_models/vaegan/train.py:109-135) = the same ConvTranspose stack with features_g = d/2, plus:
+ * the epilogue of layers 0..3 set directly (the caller folds 1/sigma of SpectralNorm, the ConvTranspose bias and
+ * BatchNorm into scale/shift), and SelfAttention (gan_models/vaegan/ops.py:86-120) on the 16 x 16 output of layer 2. */
+int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale_host, const float *shift_host);
+int gl_dcgan_set_attention(gl_dcgan *g, const float *wq_host, const float *bq_host, const float *wk_host, const float *bk_host, const float *wv_host,
+                           const float *bv_host, float gamma);
 
 /* ---------------------------------------------------------------- PGGAN generator */
 /* gan_models/pggan/model_torch.py:49-88 Generator(z_dim, in_channels, img_channels).forward(x, steps, alpha)

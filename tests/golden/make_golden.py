@@ -278,6 +278,22 @@ def make_medgan(mg):
     print("medgan hidden std", out["hidden"].std(), "decoded mean", out["decoded_binary1"].mean())
 
 
+def make_vaegan():
+    """gan_models/vaegan/train.py:109-135 Generator; two consecutive forwards (the spectral-norm state advances)"""
+    vg = _refimport.load("gan_models/vaegan/train.py", "ref_vaegan_train")
+    sd_np = synth.vaegan_state_dict(777, 100, 64)
+    g = vg.Generator(100, 64)
+    print("vaegan keys:", g.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True))
+    g.eval()
+    z = synth.latent(4, 6)
+    with torch.no_grad():
+        o1 = g(torch.from_numpy(z)).numpy()
+        o2 = g(torch.from_numpy(z)).numpy()
+    st = g.state_dict()
+    np.savez(os.path.join(HERE, "vaegan_gen.npz"), out1=o1, out2=o2, u1=st["deconv1.module.weight_u"].numpy(), v4=st["deconv4.module.weight_v"].numpy())
+    print("vaegan out std", o1.std(), "call-to-call drift", np.abs(o1 - o2).max())
+
+
 def make_png(ref_utils):
     """attack_models/utils.py:43-84: sorted path order + read_image (incl. the PIL resize branch)."""
     import PIL.Image
@@ -298,6 +314,9 @@ def make_png(ref_utils):
 
 
 if __name__ == "__main__":
+    if "--vaegan-only" in sys.argv:      # own process: its `utils` module name collides with attack_models/utils.py
+        make_vaegan()
+        sys.exit(0)
     fbb = _refimport.load("attack_models/fbb.py", "ref_fbb")
     if "--pggan-only" in sys.argv:
         make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
@@ -321,3 +340,5 @@ if __name__ == "__main__":
     make_dcgan(dc, wg)
     make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
     make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
+    import subprocess
+    subprocess.run([sys.executable, os.path.abspath(__file__), "--vaegan-only"], check=True)
