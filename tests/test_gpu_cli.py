@@ -58,3 +58,38 @@ def test_fbb_main_and_eval_roc(tmp_path, monkeypatch, synth, oracle):
     lpips.set_default_model(None)
     with pytest.raises(FileNotFoundError):
         fbb.main(args2)
+
+
+def test_generate_branch_png_bank_and_sweep(tmp_path, monkeypatch, synth):
+    """generator -> PNG bank (generate branch) -> fbb over a hyper-parameter sweep directory (fbb.py:114-123)"""
+    import ganleaks_amd as gl
+    from ganleaks_amd import bank_io
+    from ganleaks_amd.attack_models import fbb
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sweep = tmp_path / "sweep"
+    banks = {}
+    for tag, seed in (("lr_a", 1234), ("lr_b", 1235)):
+        g = Generator(100, 3, 64)
+        g.load_state_dict(synth.dcgan_state_dict(seed))
+        u8 = g.generate_u8(synth.latent(3, 70))
+        bank_io.save_png_bank(u8, str(sweep / tag))
+        banks[tag] = u8.numpy()
+    loaded, paths = bank_io.load_png_bank(str(sweep / "lr_a"), 64)
+    order = bank_io.generation_order(paths)
+    assert order[:3].tolist() == [0, 1, 10] and np.array_equal(loaded, banks["lr_a"][order])    # PNG is lossless; sorted() order
+    queries = synth.perturb_u8(4, banks["lr_a"][[3, 40]], 4.0)
+    bank_io.save_png_bank(queries, str(tmp_path / "pos"))
+    bank_io.save_png_bank(synth.lowpass_u8_images(5, 2, 64), str(tmp_path / "neg"))
+    monkeypatch.chdir(tmp_path)
+    args = fbb.parse_arguments(["--exp_name", "hp", "--syn_data_path", str(sweep), "--pos_data_dir", str(tmp_path / "pos"), "--neg_data_dir",
+                                str(tmp_path / "neg"), "--BATCH_SIZE", "64", "--distance", "l2"])
+    args.hyperparameter_search = True
+    res = fbb.main(args)
+    assert len(res) == 2
+    for tag in ("lr_a", "lr_b"):
+        out = tmp_path / "fbb_attack" / ("hp__sweep") / tag
+        assert (out / "pos_loss.npy").exists() and (out / "params.txt").exists(), out
+        nn = np.load(out / "pos_nn_idx.npy")[:, 0]
+        d_direct, i_direct = gl.attack(queries, banks[tag][bank_io.generation_order(bank_io.load_png_bank(str(sweep / tag), 64)[1])], batch_size=64)
+        assert np.array_equal(nn, i_direct)
+        assert np.array_equal(np.load(out / "pos_loss.npy")[:, 0], d_direct.astype(np.float64))
