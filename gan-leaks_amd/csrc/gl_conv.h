@@ -7,6 +7,7 @@
 struct GlGatherConv {
     // input activations, NHWC fp32: [n_img][H >> up][W >> up][Cin]
     const float *in;
+    unsigned in_bytes;          // size of the stored input tensor in bytes (filled by gl_launch_gather_conv; < 3 GiB)
     int64_t positions;          // n_img * H * W   (GEMM M: one row per base-grid position)
     int H, W, Cin;              // H, W: the convolution's input grid
     int up;                     // 1: `in` is stored at (H/2) x (W/2) and read through nearest-neighbour 2x upsampling

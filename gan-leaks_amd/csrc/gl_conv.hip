@@ -36,6 +36,7 @@ __device__ __forceinline__ int swz(int r) { return (r >> 1) & 7; }
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
+#if __HIP_DEVICE_COMPILE__   // the body uses device-only types (__amdgpu_buffer_rsrc_t); the host pass only needs the launch stub
     constexpr int BM = WAVES_M * TM * 32, BN = WAVES_N * TN * 32;
     constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, BUF_BYTES = A_BYTES + B_BYTES;
     constexpr int A_PER = BM / 32, B_PER = BN / 32;   // 16-B chunks (= 8-row pieces) each thread / wave stages per slice
@@ -62,55 +63,85 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
     const uint32_t tdy = p.tap_dy[phase], tdx = p.tap_dx[phase];
     const float *__restrict__ wp = p.wpack + (int64_t)phase * p.cols_pad * K;
 
-    // ---- per-thread staging bookkeeping: one 16-B chunk of A_PER activation rows and B_PER weight rows
+    // ---- staging through buffer_load ... lds (LDS-DMA with a buffer descriptor):
+    //   * the per-slice part of every address (tap shift, channel chunk, K offset) is wave-uniform and goes into
+    //     the instruction's scalar offset: no vector ALU work per slice for the weights, 3 ops per activation piece;
+    //   * a lane whose total offset is >= num_records gets ZEROS written to LDS by the hardware (checked on MI355X):
+    //     that is the convolution's zero padding and the ragged last position tile, with no branch and no zero page.
+    // The activation descriptor's base sits (W+1) pixels BEFORE the tensor so that the most negative tap shift still
+    // gives a non-negative scalar offset; in-image taps always land inside the real tensor.
     const int rsub = lane >> 3, slot = lane & 7;
-    int a_img[A_PER];             // first source pixel of the row's image (img * Hs * Ws)
-    int a_y[A_PER], a_x[A_PER];   // position in the convolution's input grid; y = -1000000 marks a row beyond `positions`
-    int a_chunk[A_PER];
-    const float *b_src[B_PER];
     const int up = p.up;          // 1: the input grid is the nearest-neighbour 2x upsampling of the stored tensor
     const int Hs = p.H >> up, Ws = p.W >> up;
+    constexpr unsigned kOOB = 0xC0000000u;     // voffset of a lane that must read zeros (host checks sizes < 0xC0000000)
+    const unsigned lead_bytes = (unsigned)(p.W + 1) * (unsigned)p.Cin * 4u;
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.in)) - (up ? 0 : (int64_t)lead_bytes), 0,
+                                          (int)(p.in_bytes + (up ? 0u : 2u * lead_bytes)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wp), 0, (int)((unsigned)p.cols_pad * (unsigned)K * 4u), 0x00020000);
+    unsigned a_voff[A_PER];       // up == 0: byte offset of (img, y, x, chunk) from the shifted base
+    unsigned a_mask[A_PER];       // bit t: tap t of this row falls inside the image
+    int a_img[A_PER], a_y[A_PER], a_x[A_PER], a_chunk4[A_PER];   // up == 1 only: the source pixel depends on the tap
+    unsigned b_voff[B_PER];
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
         const int r = (wave * A_PER + i) * 8 + rsub;
-        a_chunk[i] = (slot ^ swz(r)) * 4;
+        const int chunk = slot ^ swz(r);
         const int64_t pos = m0 + r;
+        a_mask[i] = 0;
+        a_voff[i] = kOOB;
+        a_img[i] = a_y[i] = a_x[i] = 0;
+        a_chunk4[i] = chunk * 16;
         if (pos < p.positions) {
             const int64_t img = pos / HW;
             const int rem = (int)(pos - img * HW);
-            a_y[i] = rem / p.W;
-            a_x[i] = rem - a_y[i] * p.W;
+            const int y = rem / p.W, x = rem - y * p.W;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int yy = y + (int)((tdy >> (2 * t)) & 3u) - 1, xx = x + (int)((tdx >> (2 * t)) & 3u) - 1;
+                if ((yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W)) a_mask[i] |= 1u << t;
+            }
+            a_voff[i] = (unsigned)pos * (unsigned)p.Cin * 4u + (unsigned)chunk * 16u;
             a_img[i] = (int)(img * Hs * Ws);
-        } else {
-            a_y[i] = -1000000;
-            a_x[i] = 0;
-            a_img[i] = 0;
+            a_y[i] = y;
+            a_x[i] = x;
         }
     }
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
         const int r = (wave * B_PER + i) * 8 + rsub;
-        b_src[i] = wp + (int64_t)(c0 + r) * K + (slot ^ swz(r)) * 4;
+        b_voff[i] = ((unsigned)(c0 + r) * (unsigned)K + (unsigned)((slot ^ swz(r)) * 4)) * 4u;
     }
 
     auto stage = [&](int kt, char *buf) {
-        // K order: taps innermost -- slice kt = (channel chunk kt / ntaps, tap kt % ntaps) -- so consecutive slices
-        // re-read the same pixels shifted by one tap while they are still in L2
+        // K order: taps innermost -- 32-channel chunk s32 / ntaps, tap s32 % ntaps (gl_conv_k_index) -- so consecutive
+        // slices re-read the same pixels shifted by one tap while they are still in L2
         const int k0 = kt * BK;
         const int tap = kt % p.ntaps;
         const int ci0 = (kt / p.ntaps) * BK;
         const int dy = (int)((tdy >> (2 * tap)) & 3u) - 1;
         const int dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
+        const unsigned tapbit = 1u << tap;
+        if (!up) {
+            const unsigned soff = (unsigned)(((dy + 1) * p.W + (dx + 1)) * p.Cin + ci0) * 4u;   // >= 0 thanks to the shifted base
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-            const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-            const bool ok = (yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W);
-            const int64_t pix = a_img[i] + (yy >> up) * Ws + (xx >> up);
-            const float *src = ok ? p.in + pix * p.Cin + ci0 + a_chunk[i] : p.zero;
-            gl_glds16(src, buf + (wave * A_PER + i) * 1024);
+            for (int i = 0; i < A_PER; ++i) {
+                const unsigned voff = (a_mask[i] & tapbit) ? a_voff[i] : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (gl_lptr)(buf + (wave * A_PER + i) * 1024), 16, voff, soff, 0, 0);
+            }
+        } else {
+            const unsigned soff = (unsigned)ci0 * 4u;
+#pragma unroll
+            for (int i = 0; i < A_PER; ++i) {
+                const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+                const unsigned pix = (unsigned)(a_img[i] + (yy >> 1) * Ws + (xx >> 1));
+                const unsigned voff = (a_mask[i] & tapbit) ? pix * (unsigned)p.Cin * 4u + (unsigned)a_chunk4[i] : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (gl_lptr)(buf + (wave * A_PER + i) * 1024), 16, voff, soff, 0, 0);
+            }
         }
+        const unsigned soff_b = (unsigned)k0 * 4u;
 #pragma unroll
-        for (int i = 0; i < B_PER; ++i) gl_glds16(b_src[i] + k0, buf + A_BYTES + (wave * B_PER + i) * 1024);
+        for (int i = 0; i < B_PER; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (gl_lptr)(buf + A_BYTES + (wave * B_PER + i) * 1024), 16, b_voff[i], soff_b, 0, 0);
     };
 
     v16f acc[TM][TN];
@@ -240,6 +271,7 @@ __global__ void __launch_bounds__(THREADS, 2) gather_conv_kernel(const GlGatherC
         if (full) store_tile(std::false_type{}, std::false_type{});
         else store_tile(std::true_type{}, std::false_type{});
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -331,14 +363,24 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
 
 }  // namespace
 
-int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases)
+int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
+    GlGatherConv p = p_in;
+    {
+        const uint64_t imgs = (uint64_t)(p.positions / ((int64_t)p.H * p.W));
+        const uint64_t bytes = imgs * (uint64_t)(p.H >> p.up) * (uint64_t)(p.W >> p.up) * (uint64_t)p.Cin * 4ull;
+        GL_REQUIRE(bytes < 0xC0000000ull, "gather_conv: input tensor of %llu bytes exceeds 3 GiB; use a smaller pass", (unsigned long long)bytes);
+        p.in_bytes = (unsigned)bytes;
+    }
     GL_REQUIRE(p.Cin % BK == 0, "gather_conv: Cin=%d must be a multiple of %d", p.Cin, BK);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv: bad phases/taps");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.wpack) & 15) == 0, "gather_conv: unaligned operand");
     GL_REQUIRE((p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31) && p.positions < (1ll << 31),
                "gather_conv: more than 2^31 positions in one launch");
     GL_REQUIRE(p.act >= 0 && p.act <= 4 && !(p.planar && p.residual), "gather_conv: bad activation code / residual with planar output");
+    GL_REQUIRE(p.in_bytes > 0 && (uint64_t)p.in_bytes + 2ull * (uint64_t)(p.W + 1) * p.Cin * 4ull < 0xC0000000ull,
+               "gather_conv: input tensor of %llu bytes exceeds the 3 GiB a buffer descriptor may span here; use a smaller pass", (unsigned long long)p.in_bytes);
+    GL_REQUIRE((uint64_t)p.cols_pad * p.ntaps * p.Cin * 4ull < 0xC0000000ull, "gather_conv: packed weights too large for one descriptor");
     GL_REQUIRE(p.up == 0 || (p.up == 1 && p.H % 2 == 0 && p.W % 2 == 0), "gather_conv: up must be 0 or 1 (even H, W)");
     if (p.planar)
         GL_REQUIRE(phases == 1 && p.omul == 1 && p.Ho == p.H && p.Wo == p.W && p.positions % 4 == 0 && p.ld_planar % 4 == 0 &&
