@@ -74,6 +74,7 @@ SIGNATURES = {
     "gl_dcgan_set_out_bias": (_i, [_p, _p]),
     "gl_dcgan_forward": (_i, [_p, _p, _i64, _p, _p]),
     "gl_dcgan_set_chunk": (_i, [_p, _i64]),
+    "gl_dcgan_set_precision": (_i, [_p, _i]),
     "gl_dcgan_set_affine": (_i, [_p, _i, _p, _p]),
     "gl_dcgan_set_attention": (_i, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float]),
     "gl_pggan_create": (_i, [_p, _i, _i, _i, _pp]),

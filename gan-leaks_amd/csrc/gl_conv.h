@@ -25,6 +25,8 @@ struct GlGatherConv {
     // planar != 0: write column-major out[c * ld_planar + position] instead (single phase, identity position map)
     int planar;
     int64_t ld_planar;
+    // gather_conv_h3 only: 0 = fp32 output (row-major or planar as above), 2 = split-fp16 layout [pos][cols/32][hi 32 | lo 32]
+    int out_mode;
     // epilogue: v = act(acc * scale[c % cmod] + shift[c % cmod]) (+ residual[same index as out], row-major only);
     // act 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh, 4 sigmoid
     const float *scale, *shift;
@@ -38,6 +40,13 @@ struct GlGatherConv {
 static inline int64_t gl_conv_k_index(int tap, int ci, int ntaps) { return ((int64_t)(ci / 32) * ntaps + tap) * 32 + (ci % 32); }
 
 int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
+
+// split-fp16 variant (gl_conv_h3.hip): `in` and `wpack` are in the split layout (see that file); same parameter block
+int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p, int phases);
+// fp32 rows [n][d] -> split layout [n][dpad/32][128 B] of (value * scale)
+int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out);
+// host: packed fp32 weight rows [rows][K] -> split layout of (value * scale); `out` holds rows * K * 4 bytes
+void gl_split_weights_host(const float *w, size_t rows, size_t K, float scale, void *out);
 
 // second half of the generator tail: col2im of P[pos][(ky*4+kx)*3+co] (the 48-column scatter-form GEMM
 // of ConvTranspose2d(Cin -> 3, k4 s2 p1)) + bias + tanh (+ 8-bit quantisation).

@@ -1,0 +1,287 @@
+// Split-fp16 ("h3") variant of the tap-gather implicit GEMM: fp32-class accuracy on the fp16 matrix cores.
+//
+//   every operand x is stored as a pair of halves  x*S ~= hi + lo,  hi = fp16(x*S), lo = fp16(x*S - hi)   (~22 mantissa bits)
+//   a*b ~= hi_a*hi_b + hi_a*lo_b + lo_a*hi_b     (the dropped lo*lo term is 2^-22 relative)
+//   three v_mfma_f32_16x16x32_f16 per 16x16 tile and 32-deep K slice, fp32 accumulation:
+//   16x the fp32-MFMA rate / 3 = 5.3x, with errors of the same class as an fp32 convolution (measured in tests).
+//
+// Storage ("split layout"): a 32-channel chunk of one position is 128 bytes = 32 hi halves then 32 lo halves, i.e. the
+// SAME byte geometry as 32 fp32 values: activations [pos][C/32][128 B], packed weights [col][K/32][128 B] with the K
+// order of gl_conv_k_index.  The gather addressing (buffer_load ... lds with scalar per-slice offsets and hardware
+// zero-fill for padding) is therefore byte-identical to gather_conv_kernel's.
+//
+// Tiling: 128 output channels x 128 positions per workgroup, 4 waves as 2 x 2, each 64 x 64 = 4 x 4 tiles of 16 x 16
+// (weights are the MFMA A operand, positions the B operand, so a lane ends up with 4 consecutive channels of one
+// position: one 8-byte store for the hi halves, one for the lo halves).  LDS rows are 128 B, chunk c of row r at slot
+// c ^ (r & 7): conflict-free ds_read_b128 (same scheme as l2_knn_i8_kernel).
+#include "gl_conv.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr int HT = 128;                 // tile edge (channels and positions)
+constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi + 64 B lo
+constexpr int HOPER = HT * HBK_BYTES;   // 16 KiB per operand per buffer
+constexpr int HTHREADS = 256;
+
+__global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
+{
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][W 16 KiB | X 16 KiB]
+
+    const unsigned inner = (unsigned)phases * (unsigned)n_tiles;
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)m_tiles * inner);
+    const int mt = (int)(id / inner);
+    const int phase = (int)((id % inner) / (unsigned)n_tiles);
+    const int nt = (int)(id % (unsigned)n_tiles);
+    const int64_t m0 = (int64_t)mt * HT;      // first position of the tile
+    const int c0 = nt * HT;                   // first output channel of the tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave >> 1, wp_ = wave & 1;          // wave position: channel half, position half
+
+    const int K = p.ntaps * p.Cin;                     // in elements; a slice is 32 elements = 128 bytes
+    const int nk = K / 32;
+    const int HW = p.H * p.W;
+    const uint32_t tdy = p.tap_dy[phase], tdx = p.tap_dx[phase];
+    const char *wbase = reinterpret_cast<const char *>(p.wpack) + (int64_t)phase * p.cols_pad * K * 4;
+
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int up = p.up;
+    const int Ws = p.W >> up, Hs = p.H >> up;
+    constexpr unsigned kOOB = 0xC0000000u;
+    const unsigned lead_bytes = (unsigned)(p.W + 1) * (unsigned)p.Cin * 4u;
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.in)) - (up ? 0 : (int64_t)lead_bytes), 0,
+                                          (int)(p.in_bytes + (up ? 0u : 2u * lead_bytes)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (int)((unsigned)p.cols_pad * (unsigned)K * 4u), 0x00020000);
+    unsigned x_voff[4], x_mask[4], w_voff[4];
+    int x_img[4], x_y[4], x_x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + rsub;
+        const int chunk = slot ^ (r & 7);
+        const int64_t pos = m0 + r;
+        x_mask[i] = 0;
+        x_voff[i] = kOOB;
+        x_img[i] = x_y[i] = x_x[i] = 0;
+        if (pos < p.positions) {
+            const int64_t img = pos / HW;
+            const int rem = (int)(pos - img * HW);
+            const int y = rem / p.W, x = rem - y * p.W;
+            for (int t = 0; t < p.ntaps; ++t) {
+                const int yy = y + (int)((tdy >> (2 * t)) & 3u) - 1, xx = x + (int)((tdx >> (2 * t)) & 3u) - 1;
+                if ((yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W)) x_mask[i] |= 1u << t;
+            }
+            x_voff[i] = (unsigned)pos * (unsigned)p.Cin * 4u + (unsigned)chunk * 16u;
+            x_img[i] = (int)(img * Hs * Ws);
+            x_y[i] = y;
+            x_x[i] = x;
+        }
+        w_voff[i] = ((unsigned)(c0 + r) * (unsigned)K) * 4u + (unsigned)chunk * 16u;
+    }
+
+    auto stage = [&](int kt, char *buf) {
+        const int tap = kt % p.ntaps;
+        const int cc = kt / p.ntaps;                   // 32-channel chunk of the input
+        const int dy = (int)((tdy >> (2 * tap)) & 3u) - 1;
+        const int dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
+        const unsigned tapbit = 1u << tap;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (gl_lptr)(buf + (wave * 4 + i) * 1024), 16, w_voff[i], (unsigned)kt * 128u, 0, 0);
+        if (!up) {
+            const unsigned soff = (unsigned)(((dy + 1) * p.W + (dx + 1)) * p.Cin) * 4u + (unsigned)cc * 128u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned voff = (x_mask[i] & tapbit) ? x_voff[i] : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + HOPER + (wave * 4 + i) * 1024), 16, voff, soff, 0, 0);
+            }
+        } else {
+            const unsigned soff = (unsigned)cc * 128u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (wave * 4 + i) * 8 + rsub;
+                const int yy = x_y[i] + dy, xx = x_x[i] + dx;
+                const unsigned pix = (unsigned)(x_img[i] + (yy >> 1) * Ws + (xx >> 1));
+                const unsigned voff = (x_mask[i] & tapbit) ? pix * (unsigned)p.Cin * 4u + (unsigned)((slot ^ (r & 7)) * 16) : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + HOPER + (wave * 4 + i) * 1024), 16, voff, soff, 0, 0);
+            }
+        }
+    };
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    stage(0, smem);
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        char *cur = smem + (kt & 1) * 2 * HOPER;
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * HOPER);
+        const char *lw = cur + (wc * 64) * HBK_BYTES;
+        const char *lx = cur + HOPER + (wp_ * 64) * HBK_BYTES;
+        v8h w_hi[4], w_lo[4], x_hi[4], x_lo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + frow;
+            w_hi[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
+            w_lo[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
+            x_hi[i] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
+            x_lo[i] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[i], x_hi[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_lo[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_hi[j], acc[i][j], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue.  C tile (16 x 16): column (position) = lane & 15, row (channel) = 4 * (lane >> 4) + reg.
+    __syncthreads();
+    int *orow = reinterpret_cast<int *>(smem);
+    if (tid < HT) {
+        const int64_t pos = m0 + tid;
+        int o = -1;
+        if (pos < p.positions) {
+            const int64_t img = pos / HW;
+            const int rem = (int)(pos - img * HW);
+            const int y = rem / p.W, x = rem - y * p.W;
+            o = (int)((img * p.Ho + (y * p.omul + p.oy[phase])) * p.Wo + (x * p.omul + p.ox[phase]));
+        }
+        orow[tid] = o;
+    }
+    __syncthreads();
+    int o4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o4[j] = orow[wp_ * 64 + j * 16 + frow];
+    const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
+    const float neg_slope = p.act == 2 ? 0.2f : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = c0 + wc * 64 + i * 16 + 4 * fk;          // first of this lane's 4 consecutive channels
+        if (ch >= p.cols) continue;                             // cols is a multiple of 4 (host-checked)
+        float sc[4], sh[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = p.scale[(ch + r) % p.cmod]; sh[r] = p.shift[(ch + r) % p.cmod]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o4[j];
+            if (o < 0) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = fmaf(acc[i][j][r], sc[r], sh[r]);
+                v[r] = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
+            }
+            if (p.out_mode == 2) {
+                // split layout: [o][cols/32][hi 32 | lo 32] halves
+                char *dst = reinterpret_cast<char *>(p.out) + (int64_t)o * p.cols * 4 + (ch >> 5) * 128 + (ch & 31) * 2;
+                v4h hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float c = fminf(fmaxf(v[r], -65504.0f), 65504.0f);
+                    hi[r] = (_Float16)c;
+                    lo[r] = (_Float16)(c - (float)hi[r]);
+                }
+                *reinterpret_cast<v4h *>(dst) = hi;
+                *reinterpret_cast<v4h *>(dst + 64) = lo;
+            } else if (p.planar) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.out[(int64_t)(ch + r) * p.ld_planar + o] = v[r];
+            } else {
+                *reinterpret_cast<float4 *>(p.out + (int64_t)o * p.cols + ch) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+#endif
+}
+
+// fp32 rows [n][d] -> split layout [n][dpad/32][hi 32 | lo 32], value * scale, zero padded to dpad
+__global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict__ in, int64_t n, int d, int dpad, float scale, char *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * dpad) return;
+    const int64_t r = i / dpad;
+    const int c = (int)(i - r * dpad);
+    const float v = c < d ? fminf(fmaxf(in[r * d + c] * scale, -65504.0f), 65504.0f) : 0.0f;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    char *dst = out + (r * dpad + (c >> 5) * 32) * 4 + (c & 31) * 2;
+    *reinterpret_cast<_Float16 *>(dst) = hi;
+    *reinterpret_cast<_Float16 *>(dst + 64) = lo;
+}
+
+}  // namespace
+
+int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
+{
+    GlGatherConv p = p_in;
+    GL_REQUIRE(p.Cin % 32 == 0, "gather_conv_h3: Cin=%d must be a multiple of 32", p.Cin);
+    GL_REQUIRE(p.cols_pad % HT == 0 && p.cols <= p.cols_pad && p.cols % 4 == 0, "gather_conv_h3: cols=%d / cols_pad=%d (multiple of %d)", p.cols, p.cols_pad, HT);
+    GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv_h3: bad phases/taps");
+    GL_REQUIRE(p.act >= 0 && p.act <= 2 && !p.residual, "gather_conv_h3: activation %d / residual not supported", p.act);
+    GL_REQUIRE(p.out_mode != 2 || p.cols % 32 == 0, "gather_conv_h3: split output needs cols %% 32 == 0");
+    GL_REQUIRE(p.up == 0 || (p.up == 1 && p.H % 2 == 0 && p.W % 2 == 0), "gather_conv_h3: up must be 0 or 1");
+    {
+        const uint64_t imgs = (uint64_t)(p.positions / ((int64_t)p.H * p.W));
+        const uint64_t bytes = imgs * (uint64_t)(p.H >> p.up) * (uint64_t)(p.W >> p.up) * (uint64_t)p.Cin * 4ull;
+        GL_REQUIRE(bytes + 2ull * (uint64_t)(p.W + 1) * p.Cin * 4ull < 0xC0000000ull, "gather_conv_h3: input of %llu bytes exceeds 3 GiB; use a smaller pass",
+                   (unsigned long long)bytes);
+        p.in_bytes = (unsigned)bytes;
+    }
+    GL_REQUIRE((uint64_t)p.cols_pad * p.ntaps * p.Cin * 4ull < 0xC0000000ull, "gather_conv_h3: packed weights too large");
+    if (p.positions == 0) return GL_OK;
+    GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
+    const int64_t m_tiles = gl_ceil_div(p.positions, HT);
+    const int n_tiles = p.cols_pad / HT;
+    GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
+    static bool attr_set = false;
+    const int lds = 4 * HOPER;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gather_conv_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
+    hipLaunchKernelGGL(gather_conv_h3_kernel, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(HTHREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles, phases);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out)
+{
+    if (n == 0) return GL_OK;
+    GL_REQUIRE(dpad % 32 == 0 && d <= dpad, "split_rows: bad padding");
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)gl_ceil_div(n * dpad, 256)), dim3(256), 0, ctx->stream, in, n, d, dpad, scale, reinterpret_cast<char *>(out));
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+// host: fp32 packed weight rows [rows][K] (K order of gl_conv_k_index, K % 32 == 0) -> split layout, value * scale
+void gl_split_weights_host(const float *w, size_t rows, size_t K, float scale, void *out)
+{
+    char *o = reinterpret_cast<char *>(out);
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t k = 0; k < K; ++k) {
+            float v = w[r * K + k] * scale;
+            if (v > 65504.0f) v = 65504.0f;
+            if (v < -65504.0f) v = -65504.0f;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            char *dst = o + (r * K + (k >> 5) * 32) * 4 + (k & 31) * 2;
+            *reinterpret_cast<_Float16 *>(dst) = hi;
+            *reinterpret_cast<_Float16 *>(dst + 64) = lo;
+        }
+}

@@ -24,7 +24,17 @@ struct gl_dcgan {
     bool have_att;
     float *att_wq, *att_bq, *att_wk, *att_bk, *att_wv, *att_bv, att_gamma;
     float *ws_att;
+    // split-fp16 path (gl_conv_h3.hip): weights in the split layout scaled by 2^wexp, epilogue constants folded for it
+    int precision;             // 0 = fp32 MFMA (exact fp32 products), 1 = split-fp16 (three fp16 MFMAs per product, ~22-bit operands)
+    float *wsplit[5];
+    int wexp[5];
+    std::vector<float> h_scale[4], h_shift[4];
+    float *scale_h3[5], *shift_h3[5];
+    bool h3_dirty;
 };
+
+// activations of the split path are stored multiplied by this power of two (keeps small values out of the fp16 subnormals)
+static const float kActScale = 16.0f;
 
 namespace {
 
@@ -167,6 +177,9 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->ws_chunk = 0;
     g->ws_z = nullptr;
     g->ws_p = nullptr;
+    g->precision = 1;
+    g->h3_dirty = true;
+    for (int l = 0; l < 5; ++l) { g->wsplit[l] = nullptr; g->wexp[l] = 0; g->scale_h3[l] = g->shift_h3[l] = nullptr; }
     g->have_att = false;
     g->att_wq = g->att_bq = g->att_wk = g->att_bk = g->att_wv = g->att_bv = nullptr;
     g->att_gamma = 0.0f;
@@ -192,6 +205,7 @@ int gl_dcgan_destroy(gl_dcgan *g)
     (void)hipFree(g->ws_z);
     (void)hipFree(g->ws_p);
     (void)hipFree(g->ws_att);
+    for (int l = 0; l < 5; ++l) { (void)hipFree(g->wsplit[l]); (void)hipFree(g->scale_h3[l]); (void)hipFree(g->shift_h3[l]); }
     (void)hipFree(g->att_wq); (void)hipFree(g->att_bq); (void)hipFree(g->att_wk); (void)hipFree(g->att_bk); (void)hipFree(g->att_wv); (void)hipFree(g->att_bv);
     (void)hipFree(g->ident_scale);
     (void)hipFree(g->ident_shift);
@@ -245,6 +259,28 @@ int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
     }
     int rc = upload(g->ctx, &g->wpack[layer], pk);
     if (rc != GL_OK) return rc;
+    {
+        // split-fp16 copy: rows padded to 128 columns, values scaled by 2^wexp so that max |w| * 2^wexp is in [2^12, 2^13)
+        const size_t Kl = layer == 0 ? (size_t)g->z_pad : (layer < 4 ? (size_t)4 * ci_n : (size_t)ci_n);
+        const size_t rows_real = pk.size() / Kl / (layer > 0 && layer < 4 ? 4 : 1);     // cols_pad of the fp32 pack, per phase
+        const size_t phases = layer > 0 && layer < 4 ? 4 : 1;
+        const size_t rows128 = (size_t)gl_ceil_div((int64_t)rows_real, 128) * 128;
+        float mx = 0.0f;
+        for (float v : pk) mx = std::fmax(mx, std::fabs(v));
+        int e = mx > 0.0f ? (int)std::floor(std::log2(8191.0f / mx)) : 0;
+        if (e > 30) e = 30;
+        if (e < -30) e = -30;
+        g->wexp[layer] = e;
+        std::vector<float> padded(phases * rows128 * Kl, 0.0f);
+        for (size_t ph = 0; ph < phases; ++ph)
+            for (size_t r = 0; r < rows_real; ++r)
+                std::copy(pk.begin() + (ph * rows_real + r) * Kl, pk.begin() + (ph * rows_real + r + 1) * Kl, padded.begin() + (ph * rows128 + r) * Kl);
+        std::vector<float> split(padded.size());
+        gl_split_weights_host(padded.data(), phases * rows128, Kl, std::ldexp(1.0f, e), split.data());
+        rc = upload(g->ctx, &g->wsplit[layer], split);
+        if (rc != GL_OK) return rc;
+        g->h3_dirty = true;
+    }
     g->have_w[layer] = true;
     return GL_OK;
 }
@@ -264,6 +300,9 @@ int gl_dcgan_set_bn(gl_dcgan *g, int layer, const float *gamma, const float *bet
     if (rc != GL_OK) return rc;
     rc = upload(g->ctx, &g->shift[layer], sh);
     if (rc != GL_OK) return rc;
+    g->h_scale[layer] = sc;
+    g->h_shift[layer] = sh;
+    g->h3_dirty = true;
     g->have_bn[layer] = true;
     return GL_OK;
 }
@@ -287,6 +326,9 @@ int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale, const float 
     int rc = upload(g->ctx, &g->scale[layer], std::vector<float>(scale, scale + c));
     if (rc == GL_OK) rc = upload(g->ctx, &g->shift[layer], std::vector<float>(shift, shift + c));
     if (rc != GL_OK) return rc;
+    g->h_scale[layer].assign(scale, scale + c);
+    g->h_shift[layer].assign(shift, shift + c);
+    g->h3_dirty = true;
     g->have_bn[layer] = true;
     return GL_OK;
 }
@@ -310,6 +352,34 @@ int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const 
     return GL_OK;
 }
 
+/* 0 = fp32 MFMA (every product exact in fp32), 1 = split-fp16 (default): operands carried as hi + lo halves (~22 bits), three fp16
+ * MFMAs per product, fp32 accumulation.  Both meet the 1e-4 parity bound; 1 is ~2-3x faster. */
+int gl_dcgan_set_precision(gl_dcgan *g, int mode)
+{
+    GL_REQUIRE(g && (mode == 0 || mode == 1), "gl_dcgan_set_precision: mode must be 0 or 1");
+    g->precision = mode;
+    return GL_OK;
+}
+
+static int dcgan_prepare_h3(gl_dcgan *g)
+{
+    if (!g->h3_dirty) return GL_OK;
+    for (int l = 0; l < 4; ++l) {
+        // stored activation = true value * kActScale; acc = 2^wexp * kActScale * conv  =>  scale' = s / 2^wexp, shift' = t * kActScale
+        std::vector<float> sc(g->h_scale[l].size()), sh(g->h_shift[l].size());
+        for (size_t i = 0; i < sc.size(); ++i) { sc[i] = std::ldexp(g->h_scale[l][i], -g->wexp[l]); sh[i] = g->h_shift[l][i] * kActScale; }
+        int rc = upload(g->ctx, &g->scale_h3[l], sc);
+        if (rc == GL_OK) rc = upload(g->ctx, &g->shift_h3[l], sh);
+        if (rc != GL_OK) return rc;
+    }
+    std::vector<float> sc(16 * g->nc, std::ldexp(1.0f / kActScale, -g->wexp[4])), sh(16 * g->nc, 0.0f);
+    int rc = upload(g->ctx, &g->scale_h3[4], sc);
+    if (rc == GL_OK) rc = upload(g->ctx, &g->shift_h3[4], sh);
+    if (rc != GL_OK) return rc;
+    g->h3_dirty = false;
+    return GL_OK;
+}
+
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev)
 {
     GL_REQUIRE(g && n >= 0, "gl_dcgan_forward: bad argument");
@@ -325,10 +395,28 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
     int rc = ensure_workspace(g, n);
     if (rc != GL_OK) return rc;
     const int64_t img_elems = (int64_t)g->nc * 64 * 64;
+    // split-fp16 path unless the caller asked for fp32 products or the (fp32) attention block sits in the stack
+    const bool h3 = g->precision == 1 && !g->have_att;
+    if (h3) {
+        rc = dcgan_prepare_h3(g);
+        if (rc != GL_OK) return rc;
+    }
+    auto launch = [&](GlGatherConv &p, int layer, int phases) {
+        if (!h3) return gl_launch_gather_conv(ctx, p, phases);
+        p.wpack = g->wsplit[layer];
+        p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128;
+        p.scale = g->scale_h3[layer];
+        p.shift = g->shift_h3[layer];
+        p.out_mode = layer < 4 ? 2 : 0;
+        return gl_launch_gather_conv_h3(ctx, p, phases);
+    };
 
     for (int64_t i0 = 0; i0 < n; i0 += g->ws_chunk) {
         const int64_t m = (n - i0 < g->ws_chunk) ? n - i0 : g->ws_chunk;
-        {
+        if (h3) {
+            rc = gl_launch_split_rows(ctx, z_dev + i0 * g->z_dim, m, g->z_dim, g->z_pad, kActScale, g->ws_z);
+            if (rc != GL_OK) return rc;
+        } else {
             const int64_t tot = m * g->z_pad;
             hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)gl_ceil_div(tot, 256)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim,
                                g->z_pad, g->ws_z);
@@ -342,7 +430,7 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
             p.tap_dy[0] = 1; p.tap_dx[0] = 1;   // offset 0
             p.out = g->ws_a[0]; p.Ho = 1; p.Wo = 1; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0;
             p.scale = g->scale[0]; p.shift = g->shift[0]; p.cmod = g->cout[0]; p.act = 1; p.zero = ctx->zero_page;
-            rc = gl_launch_gather_conv(ctx, p, 1);
+            rc = launch(p, 0, 1);
             if (rc != GL_OK) return rc;
         }
         // layers 1..3: ConvT k4 s2 p1 as four 2x2-tap sub-pixel convolutions, BN + ReLU
@@ -366,7 +454,7 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
                 }
             p.out = g->ws_a[l]; p.Ho = 2 * hw; p.Wo = 2 * hw; p.omul = 2;
             p.scale = g->scale[l]; p.shift = g->shift[l]; p.cmod = g->cout[l]; p.act = 1; p.zero = ctx->zero_page;
-            rc = gl_launch_gather_conv(ctx, p, 4);
+            rc = launch(p, l, 4);
             if (rc != GL_OK) return rc;
             hw *= 2;
             if (l == 2 && g->have_att) {
@@ -389,7 +477,7 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
             p.tap_dy[0] = 1; p.tap_dx[0] = 1;
             p.out = g->ws_p; p.Ho = hw; p.Wo = hw; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0; p.planar = 1; p.ld_planar = m * hw * hw;
             p.scale = g->ident_scale; p.shift = g->ident_shift; p.cmod = p.cols; p.act = 0; p.zero = ctx->zero_page;
-            rc = gl_launch_gather_conv(ctx, p, 1);
+            rc = launch(p, 4, 1);
             if (rc != GL_OK) return rc;
         }
         rc = gl_launch_col2im_rgb_tanh(ctx, g->ws_p, m * hw * hw, m, hw, hw, g->bias_out, out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr,

@@ -93,6 +93,10 @@ class Generator:
     def to(self, *a, **k):
         return self
 
+    def set_precision(self, mode):
+        """0 = fp32 MFMA products, 1 (default) = split-fp16 (hi + lo halves, three fp16 MFMAs per product)"""
+        check(self.ctx.lib.gl_dcgan_set_precision(self._ensure(), int(mode)))
+
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_dcgan_set_chunk(self._ensure(), int(images_per_pass)))
 

@@ -149,6 +149,10 @@ int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias_host);   /* gen.4.bias 
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev);
 /* images per internal pass (activations for that many images stay resident); 0 = default */
 int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass);
+/* arithmetic of the ConvTranspose stack: 0 = fp32 MFMA (every product exact in fp32); 1 (default) = split-fp16: operands are
+ * carried as hi + lo halves (~22 mantissa bits), three fp16 MFMAs per product, fp32 accumulation -- same error class,
+ * 2-3x faster.  Stacks with the attention block (VAEGAN) always run mode 0. */
+int gl_dcgan_set_precision(gl_dcgan *g, int mode);
 /* VAEGAN generator (gan_models/vaegan/train.py:109-135) = the same ConvTranspose stack with features_g = d/2, plus:
  * the epilogue of layers 0..3 set directly (the caller folds 1/sigma of SpectralNorm, the ConvTranspose bias and
  * BatchNorm into scale/shift), and SelfAttention (gan_models/vaegan/ops.py:86-120) on the 16 x 16 output of layer 2. */

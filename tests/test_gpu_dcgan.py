@@ -38,6 +38,26 @@ def test_generator_matches_reference(gl, synth, golden):
         assert err < ATOL, err
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_both_arithmetic_modes_match_reference(mode, gl, synth, golden, oracle):
+    """mode 0: fp32 MFMA products; mode 1 (default): split-fp16, three fp16 MFMAs per product.  Same tolerance."""
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(int(golden["weight_seed"]))
+    g = Generator(100, 3, 64)
+    g.load_state_dict(sd)
+    g.set_precision(mode)
+    z = synth.latent(int(golden["z_seed"]), int(golden["n"]))
+    out = g(z)
+    err = np.abs(out - golden["out"]).max()
+    assert err < ATOL, (mode, err)
+    z2 = synth.latent(8, 131)                      # ragged tile, more samples
+    f32, u8 = g.forward_device(z2, True, True)
+    ref = oracle.dcgan_generator_forward(sd, z2[:6])
+    err = np.abs(f32.numpy()[:6] - ref).max()
+    assert err < ATOL, (mode, err)
+    print("mode", mode, "max err vs fp64 oracle", err)
+
+
 def test_torch_tensors_and_stack(gl, synth, golden):
     import torch
     from ganleaks_amd.gan_models.dcgan.model_torch import stackGenerators
