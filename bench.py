@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--check-queries", type=int, default=64, help="queries checked against the oracle after the run")
     ap.add_argument("--gen-precision", type=int, default=1, choices=[0, 1],
                     help="generator arithmetic: 1 = split-fp16 (three fp16 MFMAs per product, default), 0 = fp32 MFMA")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal: several ranks may then share one GPU)")
     ap.add_argument("--distance", default="l2", choices=["l2", "l2-lpips"],
                     help="l2 = BASELINE configs[1] (default, the headline); l2-lpips = configs[2] (0.2*LPIPS+L2; needs ~2 MB of HBM per image)")
     args = ap.parse_args()
@@ -71,12 +73,19 @@ def main():
     from ganleaks_amd.attack_models.eval_roc import plot_roc
     from ganleaks_amd.gan_models.dcgan.model_torch import Generator
 
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)   # gloo rehearsal: ranks may share a GPU
+    if dev >= ndev:
+        raise SystemExit("rank %d needs GPU %d but only %d visible" % (rank, dev, ndev))
+    torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = gl.Context.get(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
+    ctx = gl.Context.get(dev)
     lib = ctx.lib
     p = ctypes.c_void_p
     synth = gl.synth
@@ -133,8 +142,7 @@ def main():
     out_idx = np.empty(Q, np.int64)
     keys_t = None
     if world > 1:
-        keys_t = torch.as_tensor(keys.view((Q,), np.int64), device="cuda:%d" % local_rank)
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)   # one in-order stream for kernels + RCCL
+        keys_t = torch.as_tensor(keys.view((Q,), np.int64), device="cuda:%d" % dev)
     log("[rank %d] setup %.1fs: bank rows [%d,%d) of n_eff=%d, %d queries" % (rank, time.time() - t_setup, lo, hi, n_eff, Q))
 
     ev = [ctx.event() for _ in range(4)]
@@ -158,7 +166,9 @@ def main():
         if timed_phases is not None:
             ev[2].record()
         if world > 1:
-            dist.all_reduce(keys_t, op=dist.ReduceOp.MIN)
+            ctx.sync()                                            # keys are complete on the library's stream
+            dist.all_reduce(keys_t, op=dist.ReduceOp.MIN)         # the path's one exchange step: Q packed keys (80 KB)
+            torch.cuda.current_stream().synchronize()             # reduced keys visible before the unpack kernel
         if lp_model is None:
             check(lib.gl_keys_unpack(ctx.handle, p(keys.ptr), Q, D, p(dist_dev.ptr), p(idx_dev.ptr)))
         else:
@@ -195,7 +205,7 @@ def main():
     ctx.prof_reset()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
@@ -268,7 +278,9 @@ def main():
         _, oi, os_ = c_oracle.knn_l2_u8(bank_u8.numpy(), queries_u8[sel].reshape(nchk, D), 1)
         okeys = (os_.astype(np.uint64) << np.uint64(32)) | (oi + lo).astype(np.uint64)
         if world > 1:
-            tk = torch.from_numpy(okeys.view(np.int64)).cuda()
+            tk = torch.from_numpy(okeys.view(np.int64).copy())
+            if args.backend == "nccl":
+                tk = tk.cuda()
             dist.all_reduce(tk, op=dist.ReduceOp.MIN)
             okeys = tk.cpu().numpy().view(np.uint64)
         o_idx = (okeys & np.uint64(0xFFFFFFFF)).astype(np.int64)

@@ -24,27 +24,32 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int HT = 128;                 // tile edge (channels and positions)
 constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi + 64 B lo
-constexpr int HOPER = HT * HBK_BYTES;   // 16 KiB per operand per buffer
-constexpr int HTHREADS = 256;
 
-__global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
+// WC x WP waves (channel direction x position direction), each owning 64 channels x 64 positions.
+//   <2,2>: 128 channels x 128 positions, 4 waves, 64 KiB LDS (2 workgroups per CU)
+//   <2,4>: 128 channels x 256 positions, 8 waves, 96 KiB LDS (1 workgroup per CU): 25 % less staging per MFMA
+template <int WC, int WP>
+__global__ void __launch_bounds__(64 * WC * WP, WC * WP == 4 ? 2 : 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
 #if __HIP_DEVICE_COMPILE__
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][W 16 KiB | X 16 KiB]
+    constexpr int HTC = 64 * WC, HTP = 64 * WP;        // tile: channels x positions
+    constexpr int W_BYTES = HTC * HBK_BYTES, X_BYTES = HTP * HBK_BYTES, BUF = W_BYTES + X_BYTES;
+    constexpr int NW = WC * WP;
+    constexpr int PW = (HTC / 8) / NW, PX = (HTP / 8) / NW;   // 1-KiB staging pieces per wave and slice
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][W | X]
 
     const unsigned inner = (unsigned)phases * (unsigned)n_tiles;
     const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)m_tiles * inner);
     const int mt = (int)(id / inner);
     const int phase = (int)((id % inner) / (unsigned)n_tiles);
     const int nt = (int)(id % (unsigned)n_tiles);
-    const int64_t m0 = (int64_t)mt * HT;      // first position of the tile
-    const int c0 = nt * HT;                   // first output channel of the tile
+    const int64_t m0 = (int64_t)mt * HTP;     // first position of the tile
+    const int c0 = nt * HTC;                  // first output channel of the tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave >> 1, wp_ = wave & 1;          // wave position: channel half, position half
+    const int wc = wave / WP, wp_ = wave % WP;         // wave position: channel block, position block
 
     const int K = p.ntaps * p.Cin;                     // in elements; a slice is 32 elements = 128 bytes
     const int nk = K / 32;
@@ -61,11 +66,16 @@ __global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGat
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.in)) - (up ? 0 : (int64_t)lead_bytes), 0,
                                           (int)(p.in_bytes + (up ? 0u : 2u * lead_bytes)), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (int)((unsigned)p.cols_pad * (unsigned)K * 4u), 0x00020000);
-    unsigned x_voff[4], x_mask[4], w_voff[4];
-    int x_img[4], x_y[4], x_x[4];
+    unsigned x_voff[PX], x_mask[PX], w_voff[PW];
+    int x_img[PX], x_y[PX], x_x[PX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + rsub;
+    for (int i = 0; i < PW; ++i) {
+        const int r = (wave * PW + i) * 8 + rsub;
+        w_voff[i] = ((unsigned)(c0 + r) * (unsigned)K) * 4u + (unsigned)(slot ^ (r & 7)) * 16u;
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int r = (wave * PX + i) * 8 + rsub;
         const int chunk = slot ^ (r & 7);
         const int64_t pos = m0 + r;
         x_mask[i] = 0;
@@ -84,7 +94,6 @@ __global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGat
             x_y[i] = y;
             x_x[i] = x;
         }
-        w_voff[i] = ((unsigned)(c0 + r) * (unsigned)K) * 4u + (unsigned)chunk * 16u;
     }
 
     auto stage = [&](int kt, char *buf) {
@@ -94,24 +103,24 @@ __global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGat
         const int dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
         const unsigned tapbit = 1u << tap;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (gl_lptr)(buf + (wave * 4 + i) * 1024), 16, w_voff[i], (unsigned)kt * 128u, 0, 0);
+        for (int i = 0; i < PW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (gl_lptr)(buf + (wave * PW + i) * 1024), 16, w_voff[i], (unsigned)kt * 128u, 0, 0);
         if (!up) {
             const unsigned soff = (unsigned)(((dy + 1) * p.W + (dx + 1)) * p.Cin) * 4u + (unsigned)cc * 128u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PX; ++i) {
                 const unsigned voff = (x_mask[i] & tapbit) ? x_voff[i] : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + HOPER + (wave * 4 + i) * 1024), 16, voff, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff, 0, 0);
             }
         } else {
             const unsigned soff = (unsigned)cc * 128u;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = (wave * 4 + i) * 8 + rsub;
+            for (int i = 0; i < PX; ++i) {
+                const int r = (wave * PX + i) * 8 + rsub;
                 const int yy = x_y[i] + dy, xx = x_x[i] + dx;
                 const unsigned pix = (unsigned)(x_img[i] + (yy >> 1) * Ws + (xx >> 1));
                 const unsigned voff = (x_mask[i] & tapbit) ? pix * (unsigned)p.Cin * 4u + (unsigned)((slot ^ (r & 7)) * 16) : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + HOPER + (wave * 4 + i) * 1024), 16, voff, soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff, 0, 0);
             }
         }
     };
@@ -126,10 +135,10 @@ __global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGat
     const int frow = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
-        char *cur = smem + (kt & 1) * 2 * HOPER;
-        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * HOPER);
+        char *cur = smem + (kt & 1) * BUF;
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF);
         const char *lw = cur + (wc * 64) * HBK_BYTES;
-        const char *lx = cur + HOPER + (wp_ * 64) * HBK_BYTES;
+        const char *lx = cur + W_BYTES + (wp_ * 64) * HBK_BYTES;
         v8h w_hi[4], w_lo[4], x_hi[4], x_lo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -152,7 +161,7 @@ __global__ void __launch_bounds__(HTHREADS, 2) gather_conv_h3_kernel(const GlGat
     // ---- epilogue.  C tile (16 x 16): column (position) = lane & 15, row (channel) = 4 * (lane >> 4) + reg.
     __syncthreads();
     int *orow = reinterpret_cast<int *>(smem);
-    if (tid < HT) {
+    if (tid < HTP) {
         const int64_t pos = m0 + tid;
         int o = -1;
         if (pos < p.positions) {
@@ -226,11 +235,31 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 
 }  // namespace
 
+template <int WC, int WP>
+static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
+{
+    constexpr int HTC = 64 * WC, HTP = 64 * WP;
+    const int64_t m_tiles = gl_ceil_div(p.positions, HTP);
+    const int n_tiles = p.cols_pad / HTC;
+    GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
+    static bool attr_set = false;
+    constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
+    auto kern = gather_conv_h3_kernel<WC, WP>;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(64 * WC * WP), lds, ctx->stream, p, (int)m_tiles, n_tiles, phases);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
     GlGatherConv p = p_in;
     GL_REQUIRE(p.Cin % 32 == 0, "gather_conv_h3: Cin=%d must be a multiple of 32", p.Cin);
-    GL_REQUIRE(p.cols_pad % HT == 0 && p.cols <= p.cols_pad && p.cols % 4 == 0, "gather_conv_h3: cols=%d / cols_pad=%d (multiple of %d)", p.cols, p.cols_pad, HT);
+    GL_REQUIRE(p.cols_pad % 128 == 0 && p.cols <= p.cols_pad && p.cols % 4 == 0, "gather_conv_h3: cols=%d / cols_pad=%d (multiple of 128)", p.cols, p.cols_pad);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv_h3: bad phases/taps");
     GL_REQUIRE(p.act >= 0 && p.act <= 2 && !p.residual, "gather_conv_h3: activation %d / residual not supported", p.act);
     GL_REQUIRE(p.out_mode != 2 || p.cols % 32 == 0, "gather_conv_h3: split output needs cols %% 32 == 0");
@@ -245,19 +274,9 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE((uint64_t)p.cols_pad * p.ntaps * p.Cin * 4ull < 0xC0000000ull, "gather_conv_h3: packed weights too large");
     if (p.positions == 0) return GL_OK;
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
-    const int64_t m_tiles = gl_ceil_div(p.positions, HT);
-    const int n_tiles = p.cols_pad / HT;
-    GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
-    static bool attr_set = false;
-    const int lds = 4 * HOPER;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gather_conv_h3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
-    gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
-    hipLaunchKernelGGL(gather_conv_h3_kernel, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(HTHREADS), lds, ctx->stream, p, (int)m_tiles, n_tiles, phases);
-    GL_LAUNCH_CHECK();
-    return GL_OK;
+    static const int variant = getenv("GL_H3_TILE") ? atoi(getenv("GL_H3_TILE")) : 0;   // tuning knob: 1 = 128 ch x 256 positions, 8 waves
+    if (variant == 1 && p.positions >= 65536) return launch_h3<2, 4>(ctx, p, phases);
+    return launch_h3<2, 2>(ctx, p, phases);
 }
 
 int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out)
