@@ -98,7 +98,7 @@ SIGNATURES = {
     "gl_lpips_feature_dim": (_i64, [_i, _i]),
     "gl_lpips_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_lpips_features_f32": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
-    "gl_feat_knn_f32": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gl_feat_knn": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gl_feat_rows_dist": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
 }
 

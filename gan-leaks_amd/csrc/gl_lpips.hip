@@ -9,7 +9,9 @@
 //   d(q,n) = 0.2 * sum_l mean_hw sum_c w_lc (f^q - f^n)^2 + mean_k (x_q - x_n)^2  =  |V_q - V_n|^2
 //   V = [ sqrt(0.2 w_lc / (H_l W_l)) * f_lc(h,w) / (|f_l(h,w)|_c + 1e-10)  for every tap l, position, channel ;  x_k / sqrt(D) ]
 //   (length 499 712 + 12 288 = 512 000 at 64x64), and |V_q - V_n|^2 = |V_q|^2 + |V_n|^2 - 2 V_q.V_n .
-// All arithmetic is fp32 (fp32 MFMA for the convolutions and the contraction).
+// The convolutions run on the fp32 matrix cores.  V is stored in the split-fp16 layout of gl_conv_h3.hip (every 32 values =
+// 32 hi halves + 32 lo halves of V * 2^14, the same 4 bytes per value as fp32) and the contraction runs as three fp16 MFMAs
+// per product with fp32 accumulation (~22-bit operands): fp32-class accuracy at ~2.7x the fp32-MFMA rate.
 //
 // Convolutions reuse gather_conv_kernel (gl_conv.hip): 3x3 p1 = 9 taps; the first layer (3 input channels)
 // is im2col'ed by the input kernel into one 32-wide K slice (27 values + 5 zeros).
@@ -90,9 +92,25 @@ __global__ void __launch_bounds__(256) maxpool2_nhwc_kernel(const float *__restr
     }
 }
 
-// one wave per position: f / (sqrt(sum_c f^2) + 1e-10) * coef_c  ->  V[img][off + pos*C + c]   (C % 64 == 0)
+constexpr float kVScale = 16384.0f;     // V is stored as halves of V * 2^14 (values of 1e-4 .. 1e-1 stay out of the fp16 subnormals)
+
+// element k of a split-layout row -> byte offset of its hi half (lo half: +64)
+__device__ __forceinline__ int64_t split_off(int64_t k) { return (k >> 5) * 128 + (k & 31) * 2; }
+
+__device__ __forceinline__ void split_store2(char *row, int64_t k, float a, float b)   // two consecutive elements, k even
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 hi, lo;
+    hi[0] = (_Float16)a; hi[1] = (_Float16)b;
+    lo[0] = (_Float16)(a - (float)hi[0]); lo[1] = (_Float16)(b - (float)hi[1]);
+    char *dst = row + split_off(k);
+    *reinterpret_cast<h2 *>(dst) = hi;
+    *reinterpret_cast<h2 *>(dst + 64) = lo;
+}
+
+// one wave per position: f / (sqrt(sum_c f^2) + 1e-10) * coef_c  ->  V[img][off + pos*C + c]   (C % 64 == 0), split layout
 __global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict__ f, int64_t n, int HW, int C, const float *__restrict__ coef,
-                                                        float *__restrict__ V, int64_t ldv, int64_t off)
+                                                        char *__restrict__ V, int64_t ldv_bytes, int64_t off)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -101,41 +119,60 @@ __global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict_
     for (int64_t pos = wave; pos < total; pos += nwaves) {
         const float *src = f + pos * C;
         float ss = 0.0f;
-        for (int c = lane; c < C; c += 64) { const float t = src[c]; ss = fmaf(t, t, ss); }
+        for (int c = 2 * lane; c < C; c += 128) { const float2 t = *reinterpret_cast<const float2 *>(src + c); ss = fmaf(t.x, t.x, ss); ss = fmaf(t.y, t.y, ss); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float inv = 1.0f / (sqrtf(ss) + 1e-10f);        // eps outside the sqrt (util.py:72-73)
+        const float inv = kVScale / (sqrtf(ss) + 1e-10f);        // eps outside the sqrt (util.py:72-73)
         const int64_t im = pos / HW;
-        float *dst = V + im * ldv + off + (pos - im * HW) * C;
-        for (int c = lane; c < C; c += 64) dst[c] = src[c] * inv * coef[c];
+        char *row = V + im * ldv_bytes;
+        const int64_t k0 = off + (pos - im * HW) * C;
+        for (int c = 2 * lane; c < C; c += 128) {
+            const float2 t = *reinterpret_cast<const float2 *>(src + c);
+            split_store2(row, k0 + c, t.x * inv * coef[c], t.y * inv * coef[c + 1]);
+        }
     }
 }
 
-// image part of V: x_k / sqrt(D)
+// image part of V: x_k / sqrt(D), split layout; one thread per pair of elements (D even)
 template <typename T>
-__global__ void __launch_bounds__(256) image_part_kernel(const T *__restrict__ img, int64_t n, int64_t D, float inv_sqrt_d, float *__restrict__ V, int64_t ldv,
+__global__ void __launch_bounds__(256) image_part_kernel(const T *__restrict__ img, int64_t n, int64_t D, float inv_sqrt_d, char *__restrict__ V, int64_t ldv_bytes,
                                                          int64_t off)
 {
     __shared__ float lut[256];
     lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
     __syncthreads();
-    const int64_t total = n * D;
+    const int64_t total = n * D / 2;
+    const float sc = inv_sqrt_d * kVScale;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t im = i / D;
-        V[im * ldv + off + (i - im * D)] = load_pixel(img + i, lut) * inv_sqrt_d;
+        const int64_t e = 2 * i;
+        const int64_t im = e / D;
+        const int64_t k = e - im * D;
+        split_store2(V + im * ldv_bytes, off + k, load_pixel(img + e, lut) * sc, load_pixel(img + e + 1, lut) * sc);
     }
 }
 
-// |V_row|^2: one workgroup per row, fp32 chains per thread, fp64 combine
-__global__ void __launch_bounds__(256) row_sqnorm_kernel(const float *__restrict__ V, int64_t n, int64_t K, float *__restrict__ out)
+// 8 consecutive elements of a split row (k % 8 == 0) as floats (still multiplied by kVScale)
+__device__ __forceinline__ void split_load8(const char *row, int64_t k, float (&v)[8])
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const char *src = row + (k >> 5) * 128 + (k & 31) * 2;
+    const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
+}
+
+// |V_row|^2 (unscaled): one workgroup per row, fp32 chains per thread, fp64 combine
+__global__ void __launch_bounds__(256) row_sqnorm_kernel(const char *__restrict__ V, int64_t n, int64_t K, float *__restrict__ out)
 {
     __shared__ double red[256];
     for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const float4 *p = reinterpret_cast<const float4 *>(V + r * K);
+        const char *row = V + r * K * 4;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int64_t k = threadIdx.x; k < K / 4; k += 256) {
-            const float4 v = p[k];
-            s0 = fmaf(v.x, v.x, s0); s1 = fmaf(v.y, v.y, s1); s2 = fmaf(v.z, v.z, s2); s3 = fmaf(v.w, v.w, s3);
+        for (int64_t k = (int64_t)threadIdx.x * 8; k < K; k += 256 * 8) {
+            float v[8];
+            split_load8(row, k, v);
+            s0 = fmaf(v[0], v[0], s0); s1 = fmaf(v[1], v[1], s1); s2 = fmaf(v[2], v[2], s2); s3 = fmaf(v[3], v[3], s3);
+            s0 = fmaf(v[4], v[4], s0); s1 = fmaf(v[5], v[5], s1); s2 = fmaf(v[6], v[6], s2); s3 = fmaf(v[7], v[7], s3);
         }
         red[threadIdx.x] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
         __syncthreads();
@@ -143,23 +180,30 @@ __global__ void __launch_bounds__(256) row_sqnorm_kernel(const float *__restrict
             if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) out[r] = (float)red[0];
+        if (threadIdx.x == 0) out[r] = (float)(red[0] / ((double)kVScale * (double)kVScale));
         __syncthreads();
     }
 }
 
 // per-row |V_a - V_b|^2 split at K_lp: out_lp = (sum over the LPIPS part) / 0.2, out_l2 = sum over the image part.
-// (Loss.forward's loss_lpips / loss_l2 vectors, attack_models/utils.py:173-176)
-__global__ void __launch_bounds__(256) feat_rows_dist_kernel(const float *__restrict__ Va, int64_t b, const float *__restrict__ Vb, int64_t b_gt, int64_t K,
+// (Loss.forward's loss_lpips / loss_l2 vectors, attack_models/utils.py:173-176).  K_lp and K are multiples of 8.
+__global__ void __launch_bounds__(256) feat_rows_dist_kernel(const char *__restrict__ Va, int64_t b, const char *__restrict__ Vb, int64_t b_gt, int64_t K,
                                                              int64_t K_lp, float *__restrict__ out_lp, float *__restrict__ out_l2)
 {
     __shared__ double red[2][256];
     for (int64_t r = blockIdx.x; r < b; r += gridDim.x) {
-        const float *pa = Va + r * K;
-        const float *pb = Vb + (b_gt == 1 ? 0 : r) * K;
+        const char *pa = Va + r * K * 4;
+        const char *pb = Vb + (b_gt == 1 ? 0 : r) * K * 4;
         float s_lp = 0.f, s_l2 = 0.f;
-        for (int64_t k = threadIdx.x; k < K_lp; k += 256) { const float t = pb[k] - pa[k]; s_lp = fmaf(t, t, s_lp); }
-        for (int64_t k = K_lp + threadIdx.x; k < K; k += 256) { const float t = pb[k] - pa[k]; s_l2 = fmaf(t, t, s_l2); }
+        for (int64_t k = (int64_t)threadIdx.x * 8; k < K; k += 256 * 8) {
+            float va[8], vb[8];
+            split_load8(pa, k, va);
+            split_load8(pb, k, vb);
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float t = vb[j] - va[j]; acc = fmaf(t, t, acc); }
+            if (k < K_lp) s_lp += acc; else s_l2 += acc;
+        }
         red[0][threadIdx.x] = s_lp;
         red[1][threadIdx.x] = s_l2;
         __syncthreads();
@@ -167,28 +211,27 @@ __global__ void __launch_bounds__(256) feat_rows_dist_kernel(const float *__rest
             if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
             __syncthreads();
         }
-        if (threadIdx.x == 0) { out_lp[r] = (float)(red[0][0] / 0.2); out_l2[r] = (float)red[1][0]; }
+        const double s2 = (double)kVScale * (double)kVScale;
+        if (threadIdx.x == 0) { out_lp[r] = (float)(red[0][0] / s2 / 0.2); out_l2[r] = (float)(red[1][0] / s2); }
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// pairwise |V_q - V_n|^2 + argmin on the fp32 matrix cores.
-// C[n][q] = V_n . V_q  (v_mfma_f32_32x32x2_f32), tile 128 bank rows x 128 queries, 4 waves as 2 x 2,
-// K slices of 32 floats double buffered in LDS via global_load_lds -- the main loop of gather_conv_kernel
-// with two plain row operands -- and the epilogue of l2_knn_i8_kernel:
-// dist = max(|V_q|^2 + |V_n|^2 - 2 C, 0), key = float_bits(dist) << 32 | global index, atomicMin.
+// pairwise |V_q - V_n|^2 + argmin on the fp16 matrix cores, split operands (see gl_conv_h3.hip):
+// C[n][q] = sum_k (hi_n hi_q + hi_n lo_q + lo_n hi_q) = 2^28 * V_n . V_q   (v_mfma_f32_16x16x32_f16, fp32 accumulate)
+// tile 128 bank rows x 128 queries, 4 waves as 2 x 2, each 64 x 64 = 4 x 4 tiles of 16 x 16; K slices of 32 values
+// (128 bytes) double buffered in LDS via global_load_lds (rows may lie beyond 4 GiB: no buffer descriptor here);
+// epilogue: dist = max(|V_q|^2 + |V_n|^2 - 2 C / 2^28, 0), key = float_bits(dist) << 32 | global index, atomicMin.
 // ---------------------------------------------------------------------------------------------
-typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int FT = 128, FBK = 32, FOPER = FT * FBK * 4;
-
-__device__ __forceinline__ int fswz(int r) { return (r >> 1) & 7; }
+constexpr int FT = 128, FROW = 128, FOPER = FT * FROW;
 
 __global__ void __launch_bounds__(256, 2)
-feat_knn_f32_kernel(const float *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
-                    const float *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K,
-                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K,
+                unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
@@ -199,80 +242,89 @@ feat_knn_f32_kernel(const float *__restrict__ bank, const float *__restrict__ ba
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave >> 1, wq = wave & 1;
     const int rsub = lane >> 3, slot = lane & 7;
+    const int64_t row_bytes = K * 4;
 
-    const float *a_src[4], *b_src[4];
+    const char *a_src[4], *b_src[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + rsub;
         int64_t gn = n0 + r, gq = q0 + r;
         if (gn >= n_rows) gn = n_rows - 1;      // clamped duplicates are masked in the epilogue
         if (gq >= nq) gq = nq - 1;
-        a_src[i] = bank + gn * K + (slot ^ fswz(r)) * 4;
-        b_src[i] = query + gq * K + (slot ^ fswz(r)) * 4;
+        a_src[i] = bank + gn * row_bytes + (slot ^ (r & 7)) * 16;
+        b_src[i] = query + gq * row_bytes + (slot ^ (r & 7)) * 16;
     }
-    auto stage = [&](int64_t k0, char *buf) {
+    auto stage = [&](int64_t kt, char *buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gl_glds16(a_src[i] + k0, buf + (wave * 4 + i) * 1024);
+        for (int i = 0; i < 4; ++i) gl_glds16(a_src[i] + kt * FROW, buf + (wave * 4 + i) * 1024);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + k0, buf + FOPER + (wave * 4 + i) * 1024);
+        for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + kt * FROW, buf + FOPER + (wave * 4 + i) * 1024);
     };
 
-    v16f acc[2][2];
+    v4f acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    const int64_t nk = K / FBK;
+    const int64_t nk = K / 32;
     stage(0, smem);
-    const int frow = lane & 31, fh = lane >> 5;
+    const int frow = lane & 15, fk = lane >> 4;
     for (int64_t kt = 0; kt < nk; ++kt) {
         __syncthreads();
         char *cur = smem + (kt & 1) * 2 * FOPER;
-        if (kt + 1 < nk) stage((kt + 1) * FBK, smem + ((kt + 1) & 1) * 2 * FOPER);
-        const char *la = cur + (wn * 64) * (FBK * 4);
-        const char *lb = cur + FOPER + (wq * 64) * (FBK * 4);
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * FOPER);
+        const char *la = cur + (wn * 64) * FROW;
+        const char *lb = cur + FOPER + (wq * 64) * FROW;
+        v8h a_hi[4], a_lo[4], b_hi[4], b_lo[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int chunk = 2 * g + fh;
-            v4f a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = i * 32 + frow;
-                a[i] = *reinterpret_cast<const v4f *>(la + r * (FBK * 4) + ((chunk ^ fswz(r)) << 4));
-                b[i] = *reinterpret_cast<const v4f *>(lb + r * (FBK * 4) + ((chunk ^ fswz(r)) << 4));
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + frow;
+            a_hi[i] = *reinterpret_cast<const v8h *>(la + r * FROW + ((fk ^ (r & 7)) << 4));
+            a_lo[i] = *reinterpret_cast<const v8h *>(la + r * FROW + (((4 + fk) ^ (r & 7)) << 4));
+            b_hi[i] = *reinterpret_cast<const v8h *>(lb + r * FROW + ((fk ^ (r & 7)) << 4));
+            b_lo[i] = *reinterpret_cast<const v8h *>(lb + r * FROW + (((4 + fk) ^ (r & 7)) << 4));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+            }
     }
 
-    // epilogue: C layout 32x32: column (query) = lane & 31, row (bank) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    // epilogue: C tile 16x16: column (query) = lane & 15, row (bank) = 4 * (lane >> 4) + reg
+    const float inv_s2 = 1.0f / (kVScale * kVScale);
+    const int64_t nbase = n0 + wn * 64 + fk * 4;
+    float bn[4][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t q = q0 + wq * 64 + j * 32 + frow;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t n = nbase + i * 16 + r;
+            bn[i][r] = n < n_rows ? bank_norm[n] : 0.0f;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t q = q0 + wq * 64 + j * 16 + frow;
         const float qn = q < nq ? query_norm[q] : 0.0f;
         unsigned long long best = ~0ull;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (n < n_rows) {
-                    const float d = fmaxf(fmaf(-2.0f, acc[i][j][r], __fadd_rn(qn, bank_norm[n])), 0.0f);
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
-                    best = key < best ? key : best;
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = nbase + i * 16 + r;
+                const float d = fmaxf(fmaf(-2.0f * inv_s2, acc[i][j][r], __fadd_rn(qn, bn[i][r])), 0.0f);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
+                if (n < n_rows && key < best) best = key;
             }
-        const unsigned long long o = __shfl_xor(best, 32, 64);
+        unsigned long long o = __shfl_xor(best, 16, 64);
         best = o < best ? o : best;
-        if (fh == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+        o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
     }
 }
 
@@ -387,7 +439,7 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             if (kAfter[ci] >= 1) {
                 const int C = kCout[ci];
                 hipLaunchKernelGGL(lpips_tap_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream, cur, m, h * w, C,
-                                   l->ws_coef + coef_off, Vc, K, off);
+                                   l->ws_coef + coef_off, reinterpret_cast<char *>(Vc), K * 4, off);
                 GL_LAUNCH_CHECK();
                 off += (int64_t)C * h * w;
                 coef_off += C;
@@ -403,9 +455,9 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             }
         }
         hipLaunchKernelGGL(image_part_kernel<T>, dim3((unsigned)stream_blocks(m * D)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D,
-                           (float)(1.0 / std::sqrt((double)D)), Vc, K, K_lp);
+                           (float)(1.0 / std::sqrt((double)D)), reinterpret_cast<char *>(Vc), K * 4, K_lp);
         GL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, Vc, m, K, norms_dev + i0);
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, reinterpret_cast<const char *>(Vc), m, K, norms_dev + i0);
         GL_LAUNCH_CHECK();
     }
     return GL_OK;
@@ -508,25 +560,25 @@ int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int 
     return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V_dev, norms_dev);
 }
 
-int gl_feat_knn_f32(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
+int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
                     const float *query_norm_dev, int64_t nq, int64_t K, uint64_t *keys_dev)
 {
-    GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K > 0 && K % FBK == 0, "gl_feat_knn_f32: bad sizes (K must be a multiple of %d)", FBK);
-    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn_f32: global index does not fit 32 bits");
+    GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K > 0 && K % 32 == 0, "gl_feat_knn: bad sizes (K must be a multiple of 32)");
+    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn: global index does not fit 32 bits");
     if (n_rows == 0 || nq == 0) return GL_OK;
-    GL_REQUIRE(bank_V_dev && bank_norm_dev && query_V_dev && query_norm_dev && keys_dev, "gl_feat_knn_f32: NULL device pointer");
-    GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V_dev) | reinterpret_cast<uintptr_t>(query_V_dev)) & 15) == 0, "gl_feat_knn_f32: rows must be 16-byte aligned");
+    GL_REQUIRE(bank_V_dev && bank_norm_dev && query_V_dev && query_norm_dev && keys_dev, "gl_feat_knn: NULL device pointer");
+    GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V_dev) | reinterpret_cast<uintptr_t>(query_V_dev)) & 15) == 0, "gl_feat_knn: rows must be 16-byte aligned");
     const int64_t q_tiles = gl_ceil_div(nq, FT), n_tiles = gl_ceil_div(n_rows, FT);
-    GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn_f32: grid too large");
+    GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn: grid too large");
     static bool attr_set = false;
     const int lds = 4 * FOPER;
     if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
-    hipLaunchKernelGGL(feat_knn_f32_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, bank_V_dev, bank_norm_dev, n_rows, index_base,
-                       query_V_dev, query_norm_dev, nq, K, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles);
+    hipLaunchKernelGGL(feat_knn_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, reinterpret_cast<const char *>(bank_V_dev), bank_norm_dev, n_rows,
+                       index_base, reinterpret_cast<const char *>(query_V_dev), query_norm_dev, nq, K, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -534,11 +586,11 @@ int gl_feat_knn_f32(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm
 int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,
                       float *out_l2_dev)
 {
-    GL_REQUIRE(ctx && b >= 0 && K > 0 && K_lp >= 0 && K_lp <= K, "gl_feat_rows_dist: bad sizes");
+    GL_REQUIRE(ctx && b >= 0 && K > 0 && K_lp >= 0 && K_lp <= K && K % 8 == 0 && K_lp % 8 == 0, "gl_feat_rows_dist: bad sizes");
     GL_REQUIRE(b_gt == 1 || b_gt == b, "gl_feat_rows_dist: x_gt must hold 1 row or %lld rows, got %lld", (long long)b, (long long)b_gt);
     if (b == 0) return GL_OK;
     GL_REQUIRE(V_hat_dev && V_gt_dev && out_lpips_dev && out_l2_dev, "gl_feat_rows_dist: NULL device pointer");
-    hipLaunchKernelGGL(feat_rows_dist_kernel, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, ctx->stream, V_hat_dev, b, V_gt_dev, b_gt, K, K_lp,
+    hipLaunchKernelGGL(feat_rows_dist_kernel, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, ctx->stream, reinterpret_cast<const char *>(V_hat_dev), b, reinterpret_cast<const char *>(V_gt_dev), b_gt, K, K_lp,
                        out_lpips_dev, out_l2_dev);
     GL_LAUNCH_CHECK();
     return GL_OK;

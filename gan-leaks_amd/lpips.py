@@ -143,7 +143,7 @@ def feat_knn_keys(bank, queries, n_rows=None, keys=None):
     if keys is None:
         keys = ctx.empty((max(queries.n, 1),), np.uint64)
         check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), queries.n))
-    check(ctx.lib.gl_feat_knn_f32(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
+    check(ctx.lib.gl_feat_knn(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
                                   _p(queries.norms.ptr), queries.n, bank.K, _p(keys.ptr)))
     return keys
 

@@ -207,12 +207,14 @@ int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w_host);
 int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass);
 /* length of V for H x W images: sum_l C_l H_l W_l + 3 H W  (512 000 at 64 x 64); -1 if H or W is not a multiple of 16 */
 int64_t gl_lpips_feature_dim(int H, int W);
-/* images [n][3][H][W] (8-bit codes, or fp32 in [-1,1]) -> V_dev [n][K] fp32 and norms_dev [n] = |V|^2 */
+/* images [n][3][H][W] (8-bit codes, or fp32 in [-1,1]) -> V_dev [n][K] feature rows of 4*K bytes each (opaque: every 32 values are
+ * stored as 32 hi + 32 lo halves of V * 2^14, see csrc/gl_lpips.hip) and norms_dev [n] = |V|^2 */
 int gl_lpips_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev);
 int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev);
 /* keys[q] = min(keys[q], (float_bits(max(|V_q|^2 + |V_n|^2 - 2 V_q.V_n, 0)) << 32) | (index_base + n)), n < n_rows.
- * custom_knn (attack_models/fbb.py:73-88) with Loss('l2-lpips'); unpack with gl_keys_unpack_f32. */
-int gl_feat_knn_f32(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
+ * custom_knn (attack_models/fbb.py:73-88) with Loss('l2-lpips'); unpack with gl_keys_unpack_f32.  The contraction runs as three
+ * fp16 MFMAs per product on the hi/lo halves (fp32 accumulation). */
+int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
                     const float *query_norm_dev, int64_t nq, int64_t K, uint64_t *keys_dev);
 /* Loss('l2-lpips').forward: per row, out_lpips = LPIPS and out_l2 = mean((y-x)^2) between V_hat[i] and V_gt[b_gt == 1 ? 0 : i];
  * K_lp = K - 3 H W is the length of the LPIPS part of V */
