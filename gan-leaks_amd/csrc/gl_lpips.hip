@@ -218,6 +218,116 @@ __global__ void __launch_bounds__(256) feat_rows_dist_kernel(const char *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// split-fp16 ("h3") flavour of the VGG16 pipeline: activations are stored as halves of (value * kVggAct) in the split
+// layout of gl_conv_h3.hip, so the 13 convolutions run as three fp16 MFMAs per product.
+// ---------------------------------------------------------------------------------------------
+constexpr float kVggAct = 4.0f;
+
+// image -> scaled, 3x3-im2col'ed, split layout: one 128-byte chunk (27 values + 5 zeros, hi | lo) per position
+template <typename T>
+__global__ void __launch_bounds__(256) vgg_input_split_kernel(const T *__restrict__ img, int64_t n, int H, int W, char *__restrict__ out)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
+    __syncthreads();
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * H * W) return;
+    const int64_t im = gid / (H * W);
+    const int rem = (int)(gid - im * (H * W));
+    const int y = rem / W, x = rem - y * W;
+    _Float16 hi[32], lo[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) { hi[k] = (_Float16)0.0f; lo[k] = (_Float16)0.0f; }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.0f;
+                if (ok) t = __fdiv_rn(__fsub_rn(load_pixel(img + ((im * 3 + c) * H + yy) * (int64_t)W + xx, lut), c_shift[c]), c_scale[c]) * kVggAct;
+                const _Float16 h = (_Float16)t;
+                hi[(ky * 3 + kx) * 3 + c] = h;
+                lo[(ky * 3 + kx) * 3 + c] = (_Float16)(t - (float)h);
+            }
+        }
+    uint4 *o = reinterpret_cast<uint4 *>(out + gid * 128);
+    const uint4 *ph = reinterpret_cast<const uint4 *>(hi), *pl = reinterpret_cast<const uint4 *>(lo);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = ph[k]; o[4 + k] = pl[k]; }
+}
+
+// 2x2 / stride 2 max-pool on the split layout; one thread per 8 channels of an output position (C % 32 == 0)
+__global__ void __launch_bounds__(256) maxpool2_split_kernel(const char *__restrict__ in, int64_t n, int H, int W, int C, char *__restrict__ out)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+    const int64_t total = n * Ho * Wo * C8;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        int64_t r = i / C8;
+        const int xo = (int)(r % Wo);
+        r /= Wo;
+        const int yo = (int)(r % Ho);
+        const int64_t im = r / Ho;
+        const int64_t coff = (c >> 5) * 128 + (c & 31) * 2;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -__builtin_inff();
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const char *src = in + (((im * H + 2 * yo + dy) * W + 2 * xo + dx) * (int64_t)C) * 4 + coff;
+                const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)hi[j] + (float)lo[j]);
+            }
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)m[j]; lo[j] = (_Float16)(m[j] - (float)hi[j]); }
+        char *dst = out + (((im * Ho + yo) * Wo + xo) * (int64_t)C) * 4 + coff;
+        *reinterpret_cast<h8 *>(dst) = hi;
+        *reinterpret_cast<h8 *>(dst + 64) = lo;
+    }
+}
+
+// lpips_tap_kernel for split-layout activations (values carry the factor kVggAct, which cancels in the normalisation)
+__global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__restrict__ f, int64_t n, int HW, int C, const float *__restrict__ coef,
+                                                              char *__restrict__ V, int64_t ldv_bytes, int64_t off)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t total = n * HW;
+    for (int64_t pos = wave; pos < total; pos += nwaves) {
+        const char *src = f + pos * C * 4;
+        float ss = 0.0f;
+        for (int c = 2 * lane; c < C; c += 128) {
+            const char *q = src + (c >> 5) * 128 + (c & 31) * 2;
+            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
+            const float a = (float)hi[0] + (float)lo[0], b = (float)hi[1] + (float)lo[1];
+            ss = fmaf(a, a, ss); ss = fmaf(b, b, ss);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = kVScale / (sqrtf(ss) + 1e-10f * kVggAct);        // (A f) / (|A f| + A eps) = f / (|f| + eps)
+        const int64_t im = pos / HW;
+        char *row = V + im * ldv_bytes;
+        const int64_t k0 = off + (pos - im * HW) * C;
+        for (int c = 2 * lane; c < C; c += 128) {
+            const char *q = src + (c >> 5) * 128 + (c & 31) * 2;
+            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
+            const float a = (float)hi[0] + (float)lo[0], b = (float)hi[1] + (float)lo[1];
+            split_store2(row, k0 + c, a * inv * coef[c], b * inv * coef[c + 1]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pairwise |V_q - V_n|^2 + argmin on the fp16 matrix cores, split operands (see gl_conv_h3.hip):
 // C[n][q] = sum_k (hi_n hi_q + hi_n lo_q + lo_n hi_q) = 2^28 * V_n . V_q   (v_mfma_f32_16x16x32_f16, fp32 accumulate)
 // tile 128 bank rows x 128 queries, 4 waves as 2 x 2, each 64 x 64 = 4 x 4 tiles of 16 x 16; K slices of 32 values
@@ -338,6 +448,10 @@ struct gl_lpips {
     float *lin[5];            // raw lin weights (host-checked >= 0)
     std::vector<float> lin_host[5];
     bool have_w[kNumConv], have_lin[5];
+    // split-fp16 path: weights in the split layout scaled by 2^wexp, epilogue constants 2^-wexp and bias * kVggAct
+    int precision;
+    float *wsplit[kNumConv], *scale_h3[kNumConv], *bias_h3[kNumConv];
+    int wexp[kNumConv];
     // workspace for `chunk` images of H x W
     int64_t chunk, ws_imgs;
     int ws_H, ws_W;
@@ -413,7 +527,12 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
     for (int64_t i0 = 0; i0 < n; i0 += l->ws_imgs) {
         const int64_t m = (n - i0 < l->ws_imgs) ? n - i0 : l->ws_imgs;
         float *Vc = V_dev + i0 * K;
-        hipLaunchKernelGGL(vgg_input_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W, l->ws_in);
+        const bool h3 = l->precision == 1;
+        if (h3)
+            hipLaunchKernelGGL(vgg_input_split_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W,
+                               reinterpret_cast<char *>(l->ws_in));
+        else
+            hipLaunchKernelGGL(vgg_input_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W, l->ws_in);
         GL_LAUNCH_CHECK();
         const float *cur = l->ws_in;
         float *bufs[2] = {l->ws_a, l->ws_b};
@@ -432,22 +551,36 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             }
             p.out = bufs[which]; p.Ho = h; p.Wo = w; p.omul = 1; p.oy[0] = 0; p.ox[0] = 0;
             p.scale = l->ones; p.shift = l->bias[ci]; p.cmod = kCout[ci]; p.act = 1; p.zero = ctx->zero_page;
-            rc = gl_launch_gather_conv(ctx, p, 1);
+            if (h3) {
+                p.wpack = l->wsplit[ci]; p.cols_pad = (int)gl_ceil_div(kCout[ci], 128) * 128;
+                p.scale = l->scale_h3[ci]; p.shift = l->bias_h3[ci]; p.out_mode = 2;
+                rc = gl_launch_gather_conv_h3(ctx, p, 1);
+            } else {
+                rc = gl_launch_gather_conv(ctx, p, 1);
+            }
             if (rc != GL_OK) return rc;
             cur = bufs[which];
             which ^= 1;
             if (kAfter[ci] >= 1) {
                 const int C = kCout[ci];
-                hipLaunchKernelGGL(lpips_tap_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream, cur, m, h * w, C,
-                                   l->ws_coef + coef_off, reinterpret_cast<char *>(Vc), K * 4, off);
+                if (h3)
+                    hipLaunchKernelGGL(lpips_tap_split_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream,
+                                       reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, reinterpret_cast<char *>(Vc), K * 4, off);
+                else
+                    hipLaunchKernelGGL(lpips_tap_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream, cur, m, h * w, C,
+                                       l->ws_coef + coef_off, reinterpret_cast<char *>(Vc), K * 4, off);
                 GL_LAUNCH_CHECK();
                 off += (int64_t)C * h * w;
                 coef_off += C;
             }
             if (kAfter[ci] == 2) {
                 const int C = kCout[ci];
-                hipLaunchKernelGGL(maxpool2_nhwc_kernel, dim3((unsigned)stream_blocks(m * (h / 2) * (w / 2) * (C / 4))), dim3(256), 0, ctx->stream, cur, m, h, w, C,
-                                   bufs[which]);
+                if (h3)
+                    hipLaunchKernelGGL(maxpool2_split_kernel, dim3((unsigned)stream_blocks(m * (h / 2) * (w / 2) * (C / 8))), dim3(256), 0, ctx->stream,
+                                       reinterpret_cast<const char *>(cur), m, h, w, C, reinterpret_cast<char *>(bufs[which]));
+                else
+                    hipLaunchKernelGGL(maxpool2_nhwc_kernel, dim3((unsigned)stream_blocks(m * (h / 2) * (w / 2) * (C / 4))), dim3(256), 0, ctx->stream, cur, m, h, w, C,
+                                       bufs[which]);
                 GL_LAUNCH_CHECK();
                 cur = bufs[which];
                 which ^= 1;
@@ -472,7 +605,8 @@ int gl_lpips_create(gl_ctx *ctx, gl_lpips **out)
     GL_REQUIRE(ctx && out, "gl_lpips_create: NULL argument");
     gl_lpips *l = new gl_lpips();
     l->ctx = ctx;
-    for (int i = 0; i < kNumConv; ++i) { l->w[i] = l->bias[i] = nullptr; l->have_w[i] = false; }
+    for (int i = 0; i < kNumConv; ++i) { l->w[i] = l->bias[i] = nullptr; l->have_w[i] = false; l->wsplit[i] = l->scale_h3[i] = l->bias_h3[i] = nullptr; l->wexp[i] = 0; }
+    l->precision = 1;
     for (int i = 0; i < 5; ++i) { l->lin[i] = nullptr; l->have_lin[i] = false; }
     l->ones = nullptr;
     l->chunk = 0; l->ws_imgs = 0; l->ws_H = l->ws_W = 0;
@@ -488,7 +622,7 @@ int gl_lpips_destroy(gl_lpips *l)
 {
     if (!l) return GL_OK;
     (void)hipStreamSynchronize(l->ctx->stream);
-    for (int i = 0; i < kNumConv; ++i) { (void)hipFree(l->w[i]); (void)hipFree(l->bias[i]); }
+    for (int i = 0; i < kNumConv; ++i) { (void)hipFree(l->w[i]); (void)hipFree(l->bias[i]); (void)hipFree(l->wsplit[i]); (void)hipFree(l->scale_h3[i]); (void)hipFree(l->bias_h3[i]); }
     for (int i = 0; i < 5; ++i) (void)hipFree(l->lin[i]);
     (void)hipFree(l->ones); (void)hipFree(l->ws_in); (void)hipFree(l->ws_a); (void)hipFree(l->ws_b); (void)hipFree(l->ws_coef);
     delete l;
@@ -499,6 +633,13 @@ int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass)
 {
     GL_REQUIRE(l && images_per_pass >= 0, "gl_lpips_set_chunk: bad argument");
     l->chunk = images_per_pass;
+    return GL_OK;
+}
+
+int gl_lpips_set_precision(gl_lpips *l, int mode)
+{
+    GL_REQUIRE(l && (mode == 0 || mode == 1), "gl_lpips_set_precision: mode must be 0 or 1");
+    l->precision = mode;
     return GL_OK;
 }
 
@@ -527,6 +668,25 @@ int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *
     std::vector<float> b(bias, bias + co_n);
     rc = lp_upload(l->ctx, &l->bias[conv_index], b);
     if (rc != GL_OK) return rc;
+    {
+        // split-fp16 copy: rows padded to a multiple of 128, values * 2^wexp with max |w| * 2^wexp in [2^12, 2^13)
+        const size_t Kl = conv_index == 0 ? 32 : (size_t)9 * ci_n;
+        const size_t rows128 = (size_t)gl_ceil_div(co_n, 128) * 128;
+        float mx = 0.0f;
+        for (float v : pk) mx = std::fmax(mx, std::fabs(v));
+        int e = mx > 0.0f ? (int)std::floor(std::log2(8191.0f / mx)) : 0;
+        e = e > 30 ? 30 : (e < -30 ? -30 : e);
+        l->wexp[conv_index] = e;
+        std::vector<float> padded(rows128 * Kl, 0.0f), split(rows128 * Kl);
+        std::copy(pk.begin(), pk.end(), padded.begin());
+        gl_split_weights_host(padded.data(), rows128, Kl, std::ldexp(1.0f, e), split.data());
+        rc = lp_upload(l->ctx, &l->wsplit[conv_index], split);
+        std::vector<float> sc(co_n, std::ldexp(1.0f, -e)), bh(co_n);
+        for (int c = 0; c < co_n; ++c) bh[c] = bias[c] * kVggAct;
+        if (rc == GL_OK) rc = lp_upload(l->ctx, &l->scale_h3[conv_index], sc);
+        if (rc == GL_OK) rc = lp_upload(l->ctx, &l->bias_h3[conv_index], bh);
+        if (rc != GL_OK) return rc;
+    }
     l->have_w[conv_index] = true;
     return GL_OK;
 }

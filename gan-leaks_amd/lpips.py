@@ -93,6 +93,10 @@ class LpipsModel:
         lin = torch.load(lin_path, map_location="cpu", weights_only=True)
         return cls(ctx).load_state_dicts(vgg, lin)
 
+    def set_precision(self, mode):
+        """1 (default) = split-fp16 VGG16 convolutions, 0 = fp32 MFMA"""
+        check(self.ctx.lib.gl_lpips_set_precision(self._handle, int(mode)))
+
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_lpips_set_chunk(self._handle, int(images_per_pass)))
 

@@ -205,6 +205,8 @@ int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w_host, const fl
 /* layer 0..4 = lin{layer}.model.1.weight of pretrained_models/v0.1/vgg.pth, [C] floats, all >= 0; HOST pointer */
 int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w_host);
 int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass);
+/* arithmetic of the 13 VGG16 convolutions: 1 (default) = split-fp16 (three fp16 MFMAs per product), 0 = fp32 MFMA */
+int gl_lpips_set_precision(gl_lpips *l, int mode);
 /* length of V for H x W images: sum_l C_l H_l W_l + 3 H W  (512 000 at 64 x 64); -1 if H or W is not a multiple of 16 */
 int64_t gl_lpips_feature_dim(int H, int W);
 /* images [n][3][H][W] (8-bit codes, or fp32 in [-1,1]) -> V_dev [n][K] feature rows of 4*K bytes each (opaque: every 32 values are

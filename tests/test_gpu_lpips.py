@@ -37,11 +37,15 @@ def _case(g, synth):
     return case["bank"], np.concatenate([case["pos"], case["neg"]])
 
 
+@pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("name", ["lpips_res32", "lpips_res64"])
-def test_attack_l2_lpips_matches_reference(name, gl, synth, model, golden_dir):
+def test_attack_l2_lpips_matches_reference(name, precision, gl, synth, model, golden_dir):
+    """precision 1 (default): VGG16 convolutions as split-fp16; 0: fp32 MFMA.  Same bound."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     bank, q = _case(g, synth)
+    model.set_precision(precision)
     dist, idx = gl.attack(q, bank, distance="l2-lpips", batch_size=int(g["batch_size"]), lpips=model)
+    model.set_precision(1)
     assert np.array_equal(idx, g["idx"])
     err = np.abs(dist.astype(np.float64) - g["dist"]).max()
     assert err < ATOL, err
