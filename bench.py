@@ -121,6 +121,7 @@ def main():
         from ganleaks_amd.lpips import LpipsModel
         lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
         lp_model = LpipsModel(ctx).load_state_dicts(synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
+        lp_model.set_precision(args.gen_precision)
         KF = int(lib.gl_lpips_feature_dim(64, 64))
         need_gb = (n_loc + Q) * KF * 4 / 1e9
         log("[rank %d] l2-lpips: feature vectors need %.1f GB of HBM" % (rank, need_gb))
@@ -231,13 +232,12 @@ def main():
         return e
 
     split = args.gen_precision == 1
-    conv_peak = PEAK_F16_MFMA_TFLOPS if (split and lp_model is None) else PEAK_F32_MFMA_TFLOPS
+    conv_peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     kernels = [
         # all five ConvTranspose layers run in gather_conv (the 3-channel tail as a 48-column scatter-form GEMM)
         kernel_entry("gather_conv", n_loc * (F_GATHER_PER_IMG + F_RGB_PER_IMG) + (0 if lp_model is None else (n_loc + Q) * F_VGG_PER_IMG), "mfma",
-                     conv_peak, "TFLOP/s", 1e12, 3.0 if (split and lp_model is None) else 1.0,
-                     "split-fp16: x = hi + lo, 3 fp16 MFMAs per product; achieved counts each product once, peak is the fp16 dense peak"
-                     if (split and lp_model is None) else None),
+                     conv_peak, "TFLOP/s", 1e12, 3.0 if split else 1.0,
+                     "split-fp16: x = hi + lo, 3 fp16 MFMAs per product; achieved counts each product once, peak is the fp16 dense peak" if split else None),
         kernel_entry("l2_knn", 2.0 * Q * n_loc * D, "mfma", PEAK_I8_MFMA_TOPS, "TOP/s", 1e12),
         kernel_entry("feat_knn", 0 if lp_model is None else 2.0 * Q * n_loc * KF, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s", 1e12, 3.0,
                      "split-fp16 contraction: 3 fp16 MFMAs per product"),
@@ -329,7 +329,7 @@ def main():
             "value": round(value, 2), "unit": "query-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": (("split-f16 (hi+lo, f32 accumulate; generator)" if split else "f32 (generator)") + " + i8->i32 exact (distance)") if lp_model is None
-            else "f32 (VGG16) + split-f16 (LPIPS contraction)",
+            else ("split-f16" if split else "f32") + " (generator, VGG16) + split-f16 (LPIPS contraction)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)" if lp_model is None else
                        "BASELINE configs[2] shape: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",
