@@ -246,6 +246,15 @@ def main():
         kernel_entry("l2_prepare", 2.0 * (n_loc + Q) * D, "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
     ]
     kernels = [k for k in kernels if k and k["alg_per_launch"] > 0]
+    # HBM-side traffic per launch from the PMC counters: cannot be collected from inside this process; taken from the committed
+    # rocprofv3 --pmc passes of this exact workload (profiles/r01/pmc_traffic_default.json says how), null for any other workload
+    traffic_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_default.json")
+    if os.path.exists(traffic_file) and world == 1 and Q == 10000 and N == 100000 and lp_model is None and split:
+        with open(traffic_file) as f:
+            tr = json.load(f)
+        for k in kernels:
+            if k["kernel"] in tr:
+                k["traffic"] = round(tr[k["kernel"]]["hbm_bytes_per_launch"])
     dominant = max(kernels, key=lambda k: k["avg_ms"] * k["launches"])
     roofline = {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
     for k in ("executed_mfma", "executed_frac", "note"):
