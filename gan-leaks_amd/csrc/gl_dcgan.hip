@@ -411,8 +411,11 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
         return gl_launch_gather_conv_h3(ctx, p, phases);
     };
 
-    for (int64_t i0 = 0; i0 < n; i0 += g->ws_chunk) {
-        const int64_t m = (n - i0 < g->ws_chunk) ? n - i0 : g->ws_chunk;
+    // balanced passes: ceil(n / passes) images each instead of full passes plus a small ragged one
+    const int64_t passes = gl_ceil_div(n, g->ws_chunk);
+    const int64_t per_pass = gl_ceil_div(n, passes);
+    for (int64_t i0 = 0; i0 < n; i0 += per_pass) {
+        const int64_t m = (n - i0 < per_pass) ? n - i0 : per_pass;
         if (h3) {
             rc = gl_launch_split_rows(ctx, z_dev + i0 * g->z_dim, m, g->z_dim, g->z_pad, kActScale, g->ws_z);
             if (rc != GL_OK) return rc;
