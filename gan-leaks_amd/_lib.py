@@ -83,6 +83,7 @@ SIGNATURES = {
     "gl_pggan_set_block": (_i, [_p, _i, _p, _p, _p, _p]),
     "gl_pggan_set_rgb": (_i, [_p, _i, _p, _p]),
     "gl_pggan_set_chunk": (_i, [_p, _i64]),
+    "gl_pggan_set_precision": (_i, [_p, _i]),
     "gl_pggan_forward": (_i, [_p, _p, _i64, _i, ctypes.c_float, _p, _p]),
     "gl_medgan_create": (_i, [_p, _i, _i, _i, _i, _pp]),
     "gl_medgan_destroy": (_i, [_p]),

@@ -30,6 +30,62 @@ __global__ void __launch_bounds__(256) pixelnorm_rows_kernel(const float *__rest
     for (int c = lane; c < dpad; c += 64) out[row * dpad + c] = c < d ? src[c] * inv : 0.0f;
 }
 
+// split-layout flavours (gl_conv_h3.hip): values are stored as halves of (value * kPgAct)
+constexpr float kPgAct = 16.0f;
+
+__global__ void __launch_bounds__(256) pixelnorm_rows_split_kernel(const float *__restrict__ in, int64_t n, int d, int dpad, char *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n) return;
+    const float *src = in + row * d;
+    float ss = 0.0f;
+    for (int c = lane; c < d; c += 64) { const float t = src[c]; ss = fmaf(t, t, ss); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = kPgAct / sqrtf(ss / (float)d + 1e-8f);
+    char *dst = out + row * dpad * 4;
+    for (int c = lane; c < dpad; c += 64) {
+        const float v = c < d ? src[c] * inv : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        char *q = dst + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<_Float16 *>(q) = hi;
+        *reinterpret_cast<_Float16 *>(q + 64) = (_Float16)(v - (float)hi);
+    }
+}
+
+// in place on the split layout: stored v = A x  ->  A x / sqrt(mean x^2 + eps) = A v / sqrt(mean v^2 + eps A^2); C % 64 == 0 or C == 32
+__global__ void __launch_bounds__(256) pixelnorm_split_kernel(char *__restrict__ x, int64_t positions, int C)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t pos = wave; pos < positions; pos += nwaves) {
+        char *p = x + pos * C * 4;
+        float ss = 0.0f;
+        for (int c = 2 * lane; c < C; c += 128) {
+            const char *q = p + (c >> 5) * 128 + (c & 31) * 2;
+            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
+            const float a = (float)hi[0] + (float)lo[0], b = (float)hi[1] + (float)lo[1];
+            ss = fmaf(a, a, ss); ss = fmaf(b, b, ss);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = kPgAct / sqrtf(ss / (float)C + 1e-8f * kPgAct * kPgAct);
+        for (int c = 2 * lane; c < C; c += 128) {
+            char *q = p + (c >> 5) * 128 + (c & 31) * 2;
+            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
+            const float a = ((float)hi[0] + (float)lo[0]) * inv, b = ((float)hi[1] + (float)lo[1]) * inv;
+            h2 nh, nl;
+            nh[0] = (_Float16)a; nh[1] = (_Float16)b;
+            nl[0] = (_Float16)(a - (float)nh[0]); nl[1] = (_Float16)(b - (float)nh[1]);
+            *reinterpret_cast<h2 *>(q) = nh;
+            *reinterpret_cast<h2 *>(q + 64) = nl;
+        }
+    }
+}
+
 // NHWC, in place: one wave per position
 __global__ void __launch_bounds__(256) pixelnorm_nhwc_kernel(float *__restrict__ x, int64_t positions, int C)
 {
@@ -55,9 +111,9 @@ __device__ __forceinline__ uint32_t quantize_half(float x)
     return (uint32_t)(int)t;
 }
 
-// a: [n][R][R][nc] (rgb of the last block); b: [n][R/2][R/2][nc] (rgb of its input, read through nearest x2) or NULL.
-// out NCHW.  use_tanh = 0 for steps == 0.
-__global__ void __launch_bounds__(256) pggan_output_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, int R, int nc, float alpha,
+// a: [n][R][R][ld] (rgb of the last block, ld >= nc floats per pixel); b: [n][R/2][R/2][ld] (rgb of its input, read through
+// nearest x2) or NULL.  out NCHW.  use_tanh = 0 for steps == 0.
+__global__ void __launch_bounds__(256) pggan_output_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t n, int R, int nc, int ld, float alpha,
                                                            int use_tanh, float *__restrict__ out_f32, uint8_t *__restrict__ out_u8)
 {
     const int64_t total = n * nc * R * R;
@@ -68,11 +124,11 @@ __global__ void __launch_bounds__(256) pggan_output_kernel(const float *__restri
         r /= R;
         const int c = (int)(r % nc);
         const int64_t im = r / nc;
-        float v = a[((im * R + y) * R + x) * nc + c];
+        float v = a[((im * R + y) * R + x) * ld + c];
         if (use_tanh) {
             if (b) {
                 const int Rh = R / 2;
-                const float u = b[((im * Rh + (y >> 1)) * Rh + (x >> 1)) * nc + c];
+                const float u = b[((im * Rh + (y >> 1)) * Rh + (x >> 1)) * ld + c];
                 v = __fadd_rn(__fmul_rn(alpha, v), __fmul_rn(1.0f - alpha, u));
             }
             v = tanhf(v);
@@ -108,6 +164,11 @@ std::vector<float> pack_ws(const float *w, int cout, int cin, int k)
 
 }  // namespace
 
+struct gl_pggan;
+namespace {
+int pg_make_h3(gl_pggan *g, void *h3_slot, const std::vector<float> &pk, size_t rows, size_t K, const float *bias, int nbias, bool rgb);
+}
+
 struct gl_pggan {
     gl_ctx *ctx;
     int z_dim, z_pad, C, nc;
@@ -117,6 +178,9 @@ struct gl_pggan {
     float *w_rgb[kBlocks + 1], *b_rgb[kBlocks + 1];
     bool have_init, have_blk[kBlocks], have_rgb[kBlocks + 1];
     float *ones;
+    // split-fp16 path (precision 1): per convolution the weights in the split layout (* 2^wexp) and the folded epilogue constants
+    int precision;
+    struct H3 { float *w, *scale, *shift; } h_init, h_i3, h_blk[kBlocks][2], h_rgb[kBlocks + 1];
     int64_t chunk, ws_imgs;
     size_t ws_act_elems, ws_rgb_elems;
     float *ws_z, *ws_buf[3], *ws_rgb[2];
@@ -126,8 +190,31 @@ namespace {
 
 int rgb_cin(const gl_pggan *g, int j) { return j == 0 ? g->C : g->cout[j - 1]; }
 
+// split-fp16 copy of a packed convolution: rows padded to a multiple of 128, values * 2^wexp (max |w| 2^wexp in [2^12, 2^13)),
+// epilogue constants: activations are stored * kPgAct on both sides, so scale = 2^-wexp, shift = bias * kPgAct;
+// toRGB writes true fp32 values: scale = 2^-wexp / kPgAct, shift = bias (4 columns: the 4th is padding).
+int pg_make_h3(gl_pggan *g, void *h3_slot, const std::vector<float> &pk, size_t rows, size_t K, const float *bias, int nbias, bool rgb)
+{
+    gl_pggan::H3 *h = reinterpret_cast<gl_pggan::H3 *>(h3_slot);
+    const size_t rows128 = (size_t)gl_ceil_div((int64_t)rows, 128) * 128;
+    float mx = 0.0f;
+    for (float v : pk) mx = std::fmax(mx, std::fabs(v));
+    int e = mx > 0.0f ? (int)std::floor(std::log2(8191.0f / mx)) : 0;
+    e = e > 30 ? 30 : (e < -30 ? -30 : e);
+    std::vector<float> padded(rows128 * K, 0.0f), split(rows128 * K);
+    std::copy(pk.begin(), pk.begin() + rows * K, padded.begin());
+    gl_split_weights_host(padded.data(), rows128, K, std::ldexp(1.0f, e), split.data());
+    const int nvec = rgb ? 4 : nbias;
+    std::vector<float> sc(nvec, rgb ? std::ldexp(1.0f / kPgAct, -e) : std::ldexp(1.0f, -e)), sh(nvec, 0.0f);
+    for (int i = 0; i < nbias; ++i) sh[i] = rgb ? bias[i] : bias[i] * kPgAct;
+    int rc = pg_upload(g->ctx, &h->w, split);
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &h->scale, sc);
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &h->shift, sh);
+    return rc;
+}
+
 int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int Cin, const float *w, const float *bias, int cols, int ntaps, int act,
-            float *out)
+            float *out, const gl_pggan::H3 *h3 = nullptr, bool rgb = false)
 {
     GlGatherConv p = {};
     p.in = in; p.positions = m * H * W; p.H = H; p.W = W; p.Cin = Cin; p.up = up;
@@ -140,6 +227,13 @@ int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int C
     }
     p.out = out; p.Ho = H; p.Wo = W; p.omul = 1;
     p.scale = g->ones; p.shift = bias; p.cmod = cols; p.act = act; p.zero = g->ctx->zero_page;
+    if (g->precision == 1 && h3) {
+        p.wpack = h3->w; p.scale = h3->scale; p.shift = h3->shift;
+        if (rgb) { p.cols = 4; p.cmod = 4; p.out_mode = 0; }      // 3 real + 1 padding column, fp32 [pos][4]
+        else p.out_mode = 2;
+        p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128;
+        return gl_launch_gather_conv_h3(g->ctx, p, 1);
+    }
     return gl_launch_gather_conv(g->ctx, p, 1);
 }
 
@@ -147,7 +241,10 @@ int pg_pixelnorm(gl_pggan *g, float *x, int64_t positions, int C)
 {
     int64_t blocks = gl_ceil_div(positions, 4);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(pixelnorm_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream, x, positions, C);
+    if (g->precision == 1)
+        hipLaunchKernelGGL(pixelnorm_split_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream, reinterpret_cast<char *>(x), positions, C);
+    else
+        hipLaunchKernelGGL(pixelnorm_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, g->ctx->stream, x, positions, C);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -173,6 +270,10 @@ int gl_pggan_create(gl_ctx *ctx, int z_dim, int in_channels, int img_channels, g
     g->w_init = g->b_init = g->w_i3 = g->b_i3 = nullptr;
     g->have_init = false;
     g->ones = nullptr;
+    g->precision = 1;
+    g->h_init = g->h_i3 = gl_pggan::H3{nullptr, nullptr, nullptr};
+    for (int i = 0; i < kBlocks; ++i) g->h_blk[i][0] = g->h_blk[i][1] = gl_pggan::H3{nullptr, nullptr, nullptr};
+    for (int j = 0; j <= kBlocks; ++j) g->h_rgb[j] = gl_pggan::H3{nullptr, nullptr, nullptr};
     g->chunk = 0; g->ws_imgs = 0; g->ws_act_elems = 0; g->ws_rgb_elems = 0;
     g->ws_z = nullptr; g->ws_buf[0] = g->ws_buf[1] = g->ws_buf[2] = nullptr; g->ws_rgb[0] = g->ws_rgb[1] = nullptr;
     std::vector<float> one(16 * (size_t)in_channels, 1.0f);
@@ -193,7 +294,18 @@ int gl_pggan_destroy(gl_pggan *g)
     (void)hipFree(g->ws_z);
     for (int k = 0; k < 3; ++k) (void)hipFree(g->ws_buf[k]);
     for (int k = 0; k < 2; ++k) (void)hipFree(g->ws_rgb[k]);
+    auto free_h3 = [](gl_pggan::H3 &h) { (void)hipFree(h.w); (void)hipFree(h.scale); (void)hipFree(h.shift); };
+    free_h3(g->h_init); free_h3(g->h_i3);
+    for (int i = 0; i < kBlocks; ++i) { free_h3(g->h_blk[i][0]); free_h3(g->h_blk[i][1]); }
+    for (int j = 0; j <= kBlocks; ++j) free_h3(g->h_rgb[j]);
     delete g;
+    return GL_OK;
+}
+
+int gl_pggan_set_precision(gl_pggan *g, int mode)
+{
+    GL_REQUIRE(g && (mode == 0 || mode == 1), "gl_pggan_set_precision: mode must be 0 or 1");
+    g->precision = mode;
     return GL_OK;
 }
 
@@ -215,8 +327,11 @@ int gl_pggan_set_initial(gl_pggan *g, const float *convt_w, const float *convt_b
             for (int t = 0; t < 16; ++t) pk[((size_t)t * C + co) * K + ci] = convt_w[((size_t)ci * C + co) * 16 + t];
     int rc = pg_upload(g->ctx, &g->w_init, pk);
     if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_init, std::vector<float>(convt_b, convt_b + C));
-    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->w_i3, pack_ws(ws_w, C, C, 3));
+    const std::vector<float> pk3 = pack_ws(ws_w, C, C, 3);
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->w_i3, pk3);
     if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_i3, std::vector<float>(ws_b, ws_b + C));
+    if (rc == GL_OK) rc = pg_make_h3(g, &g->h_init, pk, (size_t)16 * C, (size_t)K, convt_b, C, false);
+    if (rc == GL_OK) rc = pg_make_h3(g, &g->h_i3, pk3, (size_t)cols_pad_of(C), (size_t)9 * C, ws_b, C, false);
     if (rc != GL_OK) return rc;
     g->have_init = true;
     return GL_OK;
@@ -229,10 +344,13 @@ int gl_pggan_set_block(gl_pggan *g, int block, const float *conv1_w, const float
     const int ci = g->cin[block], co = g->cout[block];
     GL_REQUIRE(co >= 1, "gl_pggan_set_block: block %d has no channels at in_channels=%d", block, g->C);
     if (ci % 32 != 0 || co % 32 != 0) { g->have_blk[block] = false; return GL_OK; }   // too narrow for the 32-channel K slices: forward() refuses this depth
-    int rc = pg_upload(g->ctx, &g->w_blk[block][0], pack_ws(conv1_w, co, ci, 3));
+    const std::vector<float> p1 = pack_ws(conv1_w, co, ci, 3), p2 = pack_ws(conv2_w, co, co, 3);
+    int rc = pg_upload(g->ctx, &g->w_blk[block][0], p1);
     if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_blk[block][0], std::vector<float>(conv1_b, conv1_b + co));
-    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->w_blk[block][1], pack_ws(conv2_w, co, co, 3));
+    if (rc == GL_OK) rc = pg_upload(g->ctx, &g->w_blk[block][1], p2);
     if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_blk[block][1], std::vector<float>(conv2_b, conv2_b + co));
+    if (rc == GL_OK) rc = pg_make_h3(g, &g->h_blk[block][0], p1, (size_t)cols_pad_of(co), (size_t)9 * ci, conv1_b, co, false);
+    if (rc == GL_OK) rc = pg_make_h3(g, &g->h_blk[block][1], p2, (size_t)cols_pad_of(co), (size_t)9 * co, conv2_b, co, false);
     if (rc != GL_OK) return rc;
     g->have_blk[block] = true;
     return GL_OK;
@@ -245,8 +363,10 @@ int gl_pggan_set_rgb(gl_pggan *g, int j, const float *w, const float *b)
     const int ci = rgb_cin(g, j);
     GL_REQUIRE(ci >= 1, "gl_pggan_set_rgb: layer %d has no input channels", j);
     if (ci % 32 != 0) { g->have_rgb[j] = false; return GL_OK; }
-    int rc = pg_upload(g->ctx, &g->w_rgb[j], pack_ws(w, g->nc, ci, 1));
+    const std::vector<float> pr = pack_ws(w, g->nc, ci, 1);
+    int rc = pg_upload(g->ctx, &g->w_rgb[j], pr);
     if (rc == GL_OK) rc = pg_upload(g->ctx, &g->b_rgb[j], std::vector<float>(b, b + g->nc));
+    if (rc == GL_OK) rc = pg_make_h3(g, &g->h_rgb[j], pr, (size_t)cols_pad_of(g->nc), (size_t)ci, b, g->nc, true);
     if (rc != GL_OK) return rc;
     g->have_rgb[j] = true;
     return GL_OK;
@@ -282,7 +402,7 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
     int64_t want = g->chunk > 0 ? g->chunk : (int64_t)((768ull << 20) / (act * 4));   // ~768 MiB per buffer by default
     if (want < 1) want = 1;
     if (want > n) want = n;
-    const size_t rgb_elems = (size_t)R * R * nc;
+    const size_t rgb_elems = (size_t)R * R * 4;      // up to 4 floats per pixel (split path pads 3 -> 4)
     if (want > g->ws_imgs || act > g->ws_act_elems || rgb_elems > g->ws_rgb_elems) {
         GL_HIP(hipStreamSynchronize(ctx->stream));
         if (want < g->ws_imgs) want = g->ws_imgs;
@@ -305,8 +425,13 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
 
     for (int64_t i0 = 0; i0 < n; i0 += g->ws_imgs) {
         const int64_t m = (n - i0 < g->ws_imgs) ? n - i0 : g->ws_imgs;
-        hipLaunchKernelGGL(pixelnorm_rows_kernel, dim3((unsigned)gl_ceil_div(m, 4)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim, g->z_pad,
-                           g->ws_z);
+        const bool h3 = g->precision == 1;
+        if (h3)
+            hipLaunchKernelGGL(pixelnorm_rows_split_kernel, dim3((unsigned)gl_ceil_div(m, 4)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim,
+                               g->z_pad, reinterpret_cast<char *>(g->ws_z));
+        else
+            hipLaunchKernelGGL(pixelnorm_rows_kernel, dim3((unsigned)gl_ceil_div(m, 4)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim, g->z_pad,
+                               g->ws_z);
         GL_LAUNCH_CHECK();
         // ConvTranspose2d(z, C, 4, 1, 0) + bias + LeakyReLU : one GEMM to NHWC 4x4xC
         {
@@ -315,10 +440,16 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
             p.wpack = g->w_init; p.cols = 16 * C; p.cols_pad = cols_pad_of(16 * C); p.ntaps = 1; p.tap_dy[0] = 1; p.tap_dx[0] = 1;
             p.out = g->ws_buf[0]; p.Ho = 1; p.Wo = 1; p.omul = 1;
             p.scale = g->ones; p.shift = g->b_init; p.cmod = C; p.act = 2; p.zero = ctx->zero_page;
-            rc = gl_launch_gather_conv(ctx, p, 1);
+            if (h3) {
+                p.wpack = g->h_init.w; p.scale = g->h_init.scale; p.shift = g->h_init.shift; p.out_mode = 2;
+                p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128;
+                rc = gl_launch_gather_conv_h3(ctx, p, 1);
+            } else {
+                rc = gl_launch_gather_conv(ctx, p, 1);
+            }
             if (rc != GL_OK) return rc;
         }
-        rc = pg_conv(g, g->ws_buf[0], m, 4, 4, 0, C, g->w_i3, g->b_i3, C, 9, 2, g->ws_buf[1]);
+        rc = pg_conv(g, g->ws_buf[0], m, 4, 4, 0, C, g->w_i3, g->b_i3, C, 9, 2, g->ws_buf[1], &g->h_i3);
         if (rc != GL_OK) return rc;
         rc = pg_pixelnorm(g, g->ws_buf[1], m * 16, C);
         if (rc != GL_OK) return rc;
@@ -326,22 +457,22 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
         for (int s = 0; s < steps; ++s) {
             hw *= 2;
             const int b1 = (cur + 1) % 3, b2 = (cur + 2) % 3;
-            rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 1, g->cin[s], g->w_blk[s][0], g->b_blk[s][0], g->cout[s], 9, 2, g->ws_buf[b1]);
+            rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 1, g->cin[s], g->w_blk[s][0], g->b_blk[s][0], g->cout[s], 9, 2, g->ws_buf[b1], &g->h_blk[s][0]);
             if (rc == GL_OK) rc = pg_pixelnorm(g, g->ws_buf[b1], m * hw * hw, g->cout[s]);
-            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2]);
+            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2], &g->h_blk[s][1]);
             if (rc == GL_OK) rc = pg_pixelnorm(g, g->ws_buf[b2], m * hw * hw, g->cout[s]);
             if (rc != GL_OK) return rc;
             prev = cur;      // input of this block (low resolution): `upscaled` of the reference is its x2 view
             cur = b2;
         }
         // toRGB
-        rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 0, rgb_cin(g, steps), g->w_rgb[steps], g->b_rgb[steps], nc, 1, 0, g->ws_rgb[0]);
+        rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 0, rgb_cin(g, steps), g->w_rgb[steps], g->b_rgb[steps], nc, 1, 0, g->ws_rgb[0], &g->h_rgb[steps], true);
         if (rc != GL_OK) return rc;
         const float *brgb = nullptr;
         if (steps > 0 && alpha != 1.0f) {
             // rgb[steps-1](upscaled): the 1x1 convolution commutes with nearest upsampling, so it runs at half resolution.
             // With alpha == 1 the term is multiplied by exactly 0 (finite values), so it is skipped.
-            rc = pg_conv(g, g->ws_buf[prev], m, hw / 2, hw / 2, 0, rgb_cin(g, steps - 1), g->w_rgb[steps - 1], g->b_rgb[steps - 1], nc, 1, 0, g->ws_rgb[1]);
+            rc = pg_conv(g, g->ws_buf[prev], m, hw / 2, hw / 2, 0, rgb_cin(g, steps - 1), g->w_rgb[steps - 1], g->b_rgb[steps - 1], nc, 1, 0, g->ws_rgb[1], &g->h_rgb[steps - 1], true);
             if (rc != GL_OK) return rc;
             brgb = g->ws_rgb[1];
         }
@@ -349,7 +480,7 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
             const int64_t tot = m * img_elems;
             int64_t blocks = gl_ceil_div(tot, 256);
             if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(pggan_output_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g->ws_rgb[0], brgb, m, R, nc, alpha, steps > 0 ? 1 : 0,
+            hipLaunchKernelGGL(pggan_output_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, g->ws_rgb[0], brgb, m, R, nc, g->precision == 1 ? 4 : nc, alpha, steps > 0 ? 1 : 0,
                                out_f32_dev ? out_f32_dev + i0 * img_elems : nullptr, out_u8_dev ? out_u8_dev + i0 * img_elems : nullptr);
             GL_LAUNCH_CHECK();
         }

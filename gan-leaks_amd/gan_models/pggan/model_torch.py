@@ -100,6 +100,10 @@ class Generator:
     def to(self, *a, **k):
         return self
 
+    def set_precision(self, mode):
+        """1 (default) = split-fp16 convolutions, 0 = fp32 MFMA"""
+        check(self.ctx.lib.gl_pggan_set_precision(self._ensure(), int(mode)))
+
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_pggan_set_chunk(self._ensure(), int(images_per_pass)))
 

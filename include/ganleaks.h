@@ -174,6 +174,8 @@ int gl_pggan_set_block(gl_pggan *g, int block, const float *conv1_w_host, const 
 /* rgb_layers.{j}.{conv.weight [nc][C_j][1][1], bias [nc]}; j = 0 is initial_rgb */
 int gl_pggan_set_rgb(gl_pggan *g, int j, const float *w_host, const float *b_host);
 int gl_pggan_set_chunk(gl_pggan *g, int64_t images_per_pass);
+/* 1 (default) = split-fp16 convolutions (three fp16 MFMAs per product), 0 = fp32 MFMA */
+int gl_pggan_set_precision(gl_pggan *g, int mode);
 /* z_dev [n][z_dim] -> [n][nc][R][R], R = 4 * 2^steps.  out_f32_dev: what forward() returns; out_u8_dev: the bytes the
  * generate branch writes (gan_models/pggan/train.py:238-246: x*0.5+0.5, ToPILImage).  Either may be NULL. */
 int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, float alpha, float *out_f32_dev, uint8_t *out_u8_dev);

@@ -18,7 +18,9 @@ def gl():
     return ganleaks_amd
 
 
-def test_generator_matches_reference(gl, synth, golden_dir):
+@pytest.mark.parametrize("precision", [1, 0])
+def test_generator_matches_reference(precision, gl, synth, golden_dir):
+    """precision 1 (default): split-fp16 convolutions; 0: fp32 MFMA"""
     from ganleaks_amd.gan_models.pggan.model_torch import Generator, stackGenerators
     g = np.load(os.path.join(golden_dir, "pggan_gen.npz"))
     gens = {}
@@ -27,6 +29,7 @@ def test_generator_matches_reference(gl, synth, golden_dir):
         if (z_dim, C) not in gens:
             gen = Generator(z_dim, C, 3)
             assert "matched" in gen.load_state_dict(synth.pggan_state_dict(4321 + C, z_dim, C))
+            gen.set_precision(precision)
             gens[(z_dim, C)] = gen
         out = gens[(z_dim, C)](synth.latent(3, 4, z_dim), steps, float(alpha))
         ref = g["case%d" % ci]
