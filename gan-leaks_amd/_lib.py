@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
+import sys
 import threading
 
 import numpy as np
@@ -42,6 +43,7 @@ SIGNATURES = {
     "gl_ctx_set_stream": (_i, [_p, _p]),
     "gl_ctx_get_stream": (_i, [_p, _pp]),
     "gl_ctx_sync": (_i, [_p]),
+    "gl_ctx_h3_saturations": (_i, [_p, ctypes.POINTER(_i64)]),
     "gl_malloc": (_i, [_p, _sz, _pp]),
     "gl_free": (_i, [_p, _p]),
     "gl_memcpy_h2d": (_i, [_p, _p, _p, _sz]),
@@ -127,6 +129,14 @@ def load():
             raise ImportError(
                 "%s not found: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gan-leaks_amd/csrc`. "
                 "There is no CPU fallback for the attack path." % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  If this library pulls in the system
+        # ROCm runtime first, a later `import torch` ends up with a runtime it cannot initialise ("No HIP GPUs are
+        # available").  Loading torch first makes both share one runtime; without torch installed nothing changes.
+        if "torch" not in sys.modules and not os.environ.get("GANLEAKS_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError if the export is missing
@@ -179,6 +189,12 @@ class Context:
 
     def sync(self):
         check(self.lib.gl_ctx_sync(self.handle))
+
+    def h3_saturations(self):
+        """workgroups of split-fp16 kernels that clamped a value to the fp16 range since the last call (synchronises)"""
+        n = _i64(0)
+        check(self.lib.gl_ctx_h3_saturations(self.handle, ctypes.byref(n)))
+        return n.value
 
     @property
     def stream(self):

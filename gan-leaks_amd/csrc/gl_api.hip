@@ -116,6 +116,8 @@ int gl_ctx_create(int device, gl_ctx **out_ctx)
     c->stream = c->own_stream;
     GL_HIP(hipMalloc((void **)&c->zero_page, 4096));
     GL_HIP(hipMemsetAsync(c->zero_page, 0, 4096, c->stream));
+    GL_HIP(hipMalloc((void **)&c->h3_sat, 64));
+    GL_HIP(hipMemsetAsync(c->h3_sat, 0, 64, c->stream));
     GL_HIP(hipStreamSynchronize(c->stream));
     *out_ctx = c;
     return GL_OK;
@@ -129,6 +131,7 @@ int gl_ctx_destroy(gl_ctx *ctx)
     (void)gl_prof_reset(ctx);
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->zero_page);
+    (void)hipFree(ctx->h3_sat);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GL_OK;
@@ -152,6 +155,17 @@ int gl_ctx_sync(gl_ctx *ctx)
 {
     GL_REQUIRE(ctx, "gl_ctx_sync: NULL ctx");
     GL_HIP(hipStreamSynchronize(ctx->stream));
+    return GL_OK;
+}
+
+int gl_ctx_h3_saturations(gl_ctx *ctx, int64_t *out_count)
+{
+    GL_REQUIRE(ctx && out_count, "gl_ctx_h3_saturations: NULL argument");
+    int host = 0;
+    GL_HIP(hipMemcpyAsync(&host, ctx->h3_sat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    GL_HIP(hipMemsetAsync(ctx->h3_sat, 0, sizeof(int), ctx->stream));
+    GL_HIP(hipStreamSynchronize(ctx->stream));
+    *out_count = host;
     return GL_OK;
 }
 

@@ -17,6 +17,7 @@ struct gl_ctx {
     hipStream_t own_stream;
     hipStream_t stream;      // the stream work is enqueued on (own_stream or the caller's)
     float *zero_page;        // 4 KiB of zeros on the device: source for out-of-image taps
+    int *h3_sat;             // device counter: split-fp16 stores that had to clamp to the fp16 range (gl_ctx_h3_saturations)
     bool prof_on;            // gl_prof_enable: bracket tagged kernel launches with HIP events
     std::vector<gl_prof_span> prof_spans;
     std::vector<hipEvent_t> prof_pool;

@@ -27,6 +27,7 @@ struct GlGatherConv {
     int64_t ld_planar;
     // gather_conv_h3 only: 0 = fp32 output (row-major or planar as above), 2 = split-fp16 layout [pos][cols/32][hi 32 | lo 32]
     int out_mode;
+    int *sat_flag;              // filled by the launcher: counter of workgroups that clamped a split store
     // epilogue: v = act(acc * scale[c % cmod] + shift[c % cmod]) (+ residual[same index as out], row-major only);
     // act 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh, 4 sigmoid
     const float *scale, *shift;

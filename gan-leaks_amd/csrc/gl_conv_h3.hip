@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(64 * WC * WP, STAGES == 3 && WC * WP == 4 ? 1 
     for (int j = 0; j < 4; ++j) o4[j] = orow[wp_ * 64 + j * 16 + frow];
     const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
     const float neg_slope = p.act == 2 ? 0.2f : 1.0f;
+    bool saturated = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ch = c0 + wc * 64 + i * 16 + 4 * fk;          // first of this lane's 4 consecutive channels
@@ -224,6 +225,7 @@ __global__ void __launch_bounds__(64 * WC * WP, STAGES == 3 && WC * WP == 4 ? 1 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float c = fminf(fmaxf(v[r], -65504.0f), 65504.0f);
+                    saturated |= (c != v[r]);
                     hi[r] = (_Float16)c;
                     lo[r] = (_Float16)(c - (float)hi[r]);
                 }
@@ -237,6 +239,7 @@ __global__ void __launch_bounds__(64 * WC * WP, STAGES == 3 && WC * WP == 4 ? 1 
             }
         }
     }
+    if (__any(saturated) && lane == 0) atomicAdd(p.sat_flag, 1);
 #endif
 }
 
@@ -280,6 +283,7 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
     GlGatherConv p = p_in;
+    p.sat_flag = ctx->h3_sat;
     GL_REQUIRE(p.Cin % 32 == 0, "gather_conv_h3: Cin=%d must be a multiple of 32", p.Cin);
     GL_REQUIRE(p.cols_pad % 128 == 0 && p.cols <= p.cols_pad && p.cols % 4 == 0, "gather_conv_h3: cols=%d / cols_pad=%d (multiple of 128)", p.cols, p.cols_pad);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv_h3: bad phases/taps");

@@ -31,6 +31,7 @@ class Generator:
         self._ctx = ctx
         self._handle = None
         self._loaded = False
+        self._precision = 1
 
     # ---- plumbing
     @property
@@ -96,6 +97,7 @@ class Generator:
     def set_precision(self, mode):
         """0 = fp32 MFMA products, 1 (default) = split-fp16 (hi + lo halves, three fp16 MFMAs per product)"""
         check(self.ctx.lib.gl_dcgan_set_precision(self._ensure(), int(mode)))
+        self._precision = int(mode)
 
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_dcgan_set_chunk(self._ensure(), int(images_per_pass)))
@@ -107,8 +109,9 @@ class Generator:
             raise ValueError("expected z of shape [N,%d,1,1], got %s" % (self.z_dim, z.shape))
         return z, n
 
-    def forward_device(self, x, want_f32=True, want_u8=False):
-        """z -> (f32 DeviceArray [N,C,64,64] or None, u8 DeviceArray or None); asynchronous."""
+    def forward_device(self, x, want_f32=True, want_u8=False, check_range=True):
+        """z -> (f32 DeviceArray [N,C,64,64] or None, u8 DeviceArray or None).  With check_range (default) the call
+        synchronises once to make sure the split-fp16 path did not clamp any activation."""
         if not self._loaded:
             raise RuntimeError("Generator: load_state_dict() has not been called")
         z, n = self._z_device(x)
@@ -116,6 +119,12 @@ class Generator:
         f32 = self.ctx.empty(shape, np.float32) if want_f32 else None
         u8 = self.ctx.empty(shape, np.uint8) if want_u8 else None
         check(self.ctx.lib.gl_dcgan_forward(self._handle, _p(z.ptr), n, _p(f32.ptr if f32 else 0), _p(u8.ptr if u8 else 0)))
+        if check_range and self._precision == 1 and self.ctx.h3_saturations() > 0:
+            # an activation left the fp16 range of the split layout: redo this call with fp32 products
+            import warnings
+            warnings.warn("split-fp16 generator path saturated for these weights; falling back to fp32 MFMA products")
+            self.set_precision(0)
+            check(self.ctx.lib.gl_dcgan_forward(self._handle, _p(z.ptr), n, _p(f32.ptr if f32 else 0), _p(u8.ptr if u8 else 0)))
         return f32, u8
 
     def forward(self, x):

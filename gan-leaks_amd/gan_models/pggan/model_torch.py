@@ -31,6 +31,7 @@ class Generator:
         self._ctx = ctx
         self._handle = None
         self._loaded = False
+        self._precision = 1
 
     @property
     def ctx(self):
@@ -103,11 +104,12 @@ class Generator:
     def set_precision(self, mode):
         """1 (default) = split-fp16 convolutions, 0 = fp32 MFMA"""
         check(self.ctx.lib.gl_pggan_set_precision(self._ensure(), int(mode)))
+        self._precision = int(mode)
 
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_pggan_set_chunk(self._ensure(), int(images_per_pass)))
 
-    def forward_device(self, x, steps, alpha, want_f32=True, want_u8=False):
+    def forward_device(self, x, steps, alpha, want_f32=True, want_u8=False, check_range=True):
         if not self._loaded:
             raise RuntimeError("Generator: load_state_dict() has not been called")
         z = as_device(self.ctx, x, np.float32)
@@ -118,8 +120,15 @@ class Generator:
         shape = (n, self.img_channels, R, R)
         f32 = self.ctx.empty(shape, np.float32) if want_f32 else None
         u8 = self.ctx.empty(shape, np.uint8) if want_u8 else None
-        check(self.ctx.lib.gl_pggan_forward(self._handle, _p(z.ptr), n, int(steps), ctypes.c_float(alpha), _p(f32.ptr if f32 else 0),
-                                            _p(u8.ptr if u8 else 0)))
+        def run():
+            check(self.ctx.lib.gl_pggan_forward(self._handle, _p(z.ptr), n, int(steps), ctypes.c_float(alpha), _p(f32.ptr if f32 else 0),
+                                                _p(u8.ptr if u8 else 0)))
+        run()
+        if check_range and self._precision == 1 and self.ctx.h3_saturations() > 0:
+            import warnings
+            warnings.warn("split-fp16 generator path saturated for these weights; falling back to fp32 MFMA products")
+            self.set_precision(0)
+            run()
         return f32, u8
 
     def forward(self, x, steps, alpha):

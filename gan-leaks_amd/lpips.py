@@ -50,6 +50,7 @@ class LpipsModel:
         check(self.ctx.lib.gl_lpips_create(self.ctx.handle, ctypes.byref(h)))
         self._handle = h
         self._loaded = False
+        self._precision = 1
 
     def __del__(self):
         if getattr(self, "_handle", None) is not None:
@@ -96,6 +97,7 @@ class LpipsModel:
     def set_precision(self, mode):
         """1 (default) = split-fp16 VGG16 convolutions, 0 = fp32 MFMA"""
         check(self.ctx.lib.gl_lpips_set_precision(self._handle, int(mode)))
+        self._precision = int(mode)
 
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_lpips_set_chunk(self._handle, int(images_per_pass)))
@@ -119,10 +121,17 @@ class LpipsModel:
             u8, bad = encode_if_lattice(ctx, rows)
             if bad == 0:
                 rows = u8
-        if rows.dtype == np.uint8:
-            check(ctx.lib.gl_lpips_features_u8(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
-        else:
-            check(ctx.lib.gl_lpips_features_f32(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+        def run():
+            if rows.dtype == np.uint8:
+                check(ctx.lib.gl_lpips_features_u8(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+            else:
+                check(ctx.lib.gl_lpips_features_f32(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+        run()
+        if self._precision == 1 and ctx.h3_saturations() > 0:
+            import warnings
+            warnings.warn("split-fp16 VGG16 path saturated for these weights; falling back to fp32 MFMA products")
+            self.set_precision(0)
+            run()
         return FeatureBank(ctx, V, norms, n, K, K - 3 * H * W, index_base)
 
 

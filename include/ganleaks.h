@@ -53,6 +53,11 @@ int gl_ctx_set_stream(gl_ctx *ctx, void *hip_stream);      /* NULL restores the 
 int gl_ctx_get_stream(gl_ctx *ctx, void **out_hip_stream);
 int gl_ctx_sync(gl_ctx *ctx);                              /* hipStreamSynchronize */
 
+/* split-fp16 kernels store activations as fp16 halves of (value * 2^k); a value beyond the fp16 range is clamped and counted.
+ * Returns (and resets) the number of workgroups that clamped since the last call; synchronises.  Non-zero means the result of
+ * the split path is not trustworthy for these weights: rerun with gl_*_set_precision(.., 0). */
+int gl_ctx_h3_saturations(gl_ctx *ctx, int64_t *out_count);
+
 /* device memory + copies (synchronous w.r.t. the context stream) */
 int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev);
 int gl_free(gl_ctx *ctx, void *dev);

@@ -152,3 +152,22 @@ def test_end_to_end_generator_bank_attack(gl, synth, oracle, coracle_mod):
 def coracle_mod():
     import c_oracle
     return c_oracle
+
+
+def test_split_path_saturation_falls_back(gl, synth, oracle):
+    """weights that drive an activation beyond the fp16 range of the split layout: detected, redone with fp32 products"""
+    import warnings
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(3)
+    sd["gen.1.1.weight"] = sd["gen.1.1.weight"] * 4000.0      # BatchNorm gain -> activations of ~1e4 (x16 in the split layout > 65504)
+    sd["gen.2.0.weight"] = sd["gen.2.0.weight"] / 4000.0      # next layer scales them back: the fp32 result is ordinary
+    g = Generator(100, 3, 64)
+    g.load_state_dict(sd)
+    z = synth.latent(4, 5)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        out = g(z)
+    assert any("saturated" in str(x.message) for x in w)
+    ref = oracle.dcgan_generator_forward(sd, z)
+    assert np.abs(out - ref).max() < 5e-5
+    assert g._precision == 0
