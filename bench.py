@@ -54,6 +54,9 @@ def main():
                     help="generator arithmetic: 1 = split-fp16 (three fp16 MFMAs per product, default), 0 = fp32 MFMA")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal: several ranks may then share one GPU)")
+    ap.add_argument("--feat-rows", default="fp16", choices=["fp16", "split"],
+                    help="l2-lpips only: rows of the nearest-neighbour search: fp16 = one half per LPIPS value (gl_feat_knn_h1, default), "
+                         "split = hi + lo halves of everything (gl_feat_knn)")
     ap.add_argument("--distance", default="l2", choices=["l2", "l2-lpips"],
                     help="l2 = BASELINE configs[1] (default, the headline); l2-lpips = configs[2] (0.2*LPIPS+L2; needs ~2 MB of HBM per image)")
     args = ap.parse_args()
@@ -122,12 +125,15 @@ def main():
         lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
         lp_model = LpipsModel(ctx).load_state_dicts(synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
         lp_model.set_precision(args.gen_precision)
-        KF = int(lib.gl_lpips_feature_dim(64, 64))
-        need_gb = (n_loc + Q) * KF * 4 / 1e9
+        KF_ALG = int(lib.gl_lpips_feature_dim(64, 64))          # 512 000: the contraction length the roofline is priced on
+        h1 = args.feat_rows == "fp16"
+        KF = int(lib.gl_lpips_search_dim(64, 64)) if h1 else KF_ALG
+        row_dtype = np.float16 if h1 else np.float32
+        need_gb = (n_loc + Q) * KF * np.dtype(row_dtype).itemsize / 1e9
         log("[rank %d] l2-lpips: feature vectors need %.1f GB of HBM" % (rank, need_gb))
-        bank_V = ctx.empty((n_loc, KF), np.float32)
+        bank_V = ctx.empty((n_loc, KF), row_dtype)
         bank_Vn = ctx.empty((n_loc,), np.float32)
-        q_V = ctx.empty((Q, KF), np.float32)
+        q_V = ctx.empty((Q, KF), row_dtype)
         q_Vn = ctx.empty((Q,), np.float32)
 
     stride = int(lib.gl_l2_row_stride(D))
@@ -160,10 +166,15 @@ def main():
             check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
             check(lib.gl_l2_knn_i8(ctx.handle, p(bank_i8.ptr), p(bank_nrm.ptr), n_loc, lo, p(q_i8.ptr), p(q_nrm.ptr), Q, D, p(keys.ptr)))
         else:
-            check(lib.gl_lpips_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
-            check(lib.gl_lpips_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
+            if h1:
+                check(lib.gl_lpips_search_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, 1, p(bank_V.ptr), p(bank_Vn.ptr)))
+                check(lib.gl_lpips_search_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, 0, p(q_V.ptr), p(q_Vn.ptr)))
+            else:
+                check(lib.gl_lpips_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
+                check(lib.gl_lpips_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
             check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
-            check(lib.gl_feat_knn(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr)))
+            knn = lib.gl_feat_knn_h1 if h1 else lib.gl_feat_knn
+            check(knn(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr)))
         if timed_phases is not None:
             ev[2].record()
         if world > 1:
@@ -239,8 +250,11 @@ def main():
                      conv_peak, "TFLOP/s", 1e12, 3.0 if split else 1.0,
                      "split-fp16: x = hi + lo, 3 fp16 MFMAs per product; achieved counts each product once, peak is the fp16 dense peak" if split else None),
         kernel_entry("l2_knn", 2.0 * Q * n_loc * D, "mfma", PEAK_I8_MFMA_TOPS, "TOP/s", 1e12),
-        kernel_entry("feat_knn", 0 if lp_model is None else 2.0 * Q * n_loc * KF, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s", 1e12, 3.0,
-                     "split-fp16 contraction: 3 fp16 MFMAs per product"),
+        # algorithmic length 512 000 (K_lpips + D); search rows issue 536 576 / 512 000 MFMA products per algorithmic one, split rows 3
+        kernel_entry("feat_knn", 0 if lp_model is None else 2.0 * Q * n_loc * KF_ALG, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s", 1e12,
+                     1.0 if lp_model is None else (KF / KF_ALG if h1 else 3.0),
+                     None if lp_model is None else ("fp16 search rows: one MFMA per LPIPS product, three for the 12 288 image values" if h1
+                                                    else "split-fp16 contraction: 3 fp16 MFMAs per product")),
         # col2im + tanh + quantise: reads P [1024][48] fp32, writes 12288 codes per image
         kernel_entry("convt_rgb", n_loc * (1024 * 48 * 4 + 12288.0), "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
         kernel_entry("l2_prepare", 2.0 * (n_loc + Q) * D, "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
@@ -338,7 +352,7 @@ def main():
             "value": round(value, 2), "unit": "query-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": (("split-f16 (hi+lo, f32 accumulate; generator)" if split else "f32 (generator)") + " + i8->i32 exact (distance)") if lp_model is None
-            else ("split-f16" if split else "f32") + " (generator, VGG16) + split-f16 (LPIPS contraction)",
+            else ("split-f16" if split else "f32") + " (generator, VGG16) + " + ("f16 search rows" if args.feat_rows == "fp16" else "split-f16") + " (LPIPS contraction)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)" if lp_model is None else
                        "BASELINE configs[2] shape: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",

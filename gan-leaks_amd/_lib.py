@@ -103,6 +103,10 @@ SIGNATURES = {
     "gl_lpips_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_lpips_features_f32": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_feat_knn": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gl_lpips_search_dim": (_i64, [_i, _i]),
+    "gl_lpips_search_features_u8": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
+    "gl_lpips_search_features_f32": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
+    "gl_feat_knn_h1": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gl_feat_rows_dist": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
 }
 

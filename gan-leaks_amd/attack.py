@@ -188,8 +188,9 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
     if distance == "l2-lpips":
         from . import lpips as _lp
         model = lpips or _lp.default_model()
-        fb = bank if prepared else model.features(bank)
-        fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries)
+        fb = bank if prepared else model.features(bank, role=model.search_role("bank"))
+        q_role = "query" if getattr(fb, "role", None) else None          # queries follow the bank's row format
+        fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=q_role)
         keys = _lp.feat_knn_keys(fb, fq, n_rows)
         if reduce_fn is not None:
             keys = reduce_fn(keys)

@@ -75,7 +75,7 @@ def _cached_bank(syn_imgs, n_rows, loss):
     key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows, loss.distance, id(loss.lpips_model))
     if _bank_cache["key"] != key:
         if loss.distance == "l2-lpips":
-            _bank_cache["bank"] = loss.lpips_model.features(syn_imgs[:n_rows])
+            _bank_cache["bank"] = loss.lpips_model.features(syn_imgs[:n_rows], role=loss.lpips_model.search_role("bank"))
         else:
             _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows], keep_u8=True)
         _bank_cache["key"] = key
@@ -137,7 +137,7 @@ def main(args):
         if n_rows == 0:
             raise ValueError("torch.cat(): expected a non-empty list of Tensors")
         if distance == "l2-lpips":
-            bank = custom_loss.lpips_model.features(syn_imgs[:n_rows])
+            bank = custom_loss.lpips_model.features(syn_imgs[:n_rows], role=custom_loss.lpips_model.search_role("bank"))
         else:
             bank = Bank.from_images(syn_imgs[:n_rows])
 

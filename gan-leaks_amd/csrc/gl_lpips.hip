@@ -108,7 +108,22 @@ __device__ __forceinline__ void split_store2(char *row, int64_t k, float a, floa
     *reinterpret_cast<h2 *>(dst + 64) = lo;
 }
 
+// "search" rows (H1 = true): one fp16 per value (V * 2^14 rounded once), K contiguous -- the operand of feat_knn_h1_kernel
+template <bool H1>
+__device__ __forceinline__ void v_store2(char *row, int64_t k, float a, float b)
+{
+    if constexpr (H1) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 h;
+        h[0] = (_Float16)a; h[1] = (_Float16)b;
+        *reinterpret_cast<h2 *>(row + k * 2) = h;
+    } else {
+        split_store2(row, k, a, b);
+    }
+}
+
 // one wave per position: f / (sqrt(sum_c f^2) + 1e-10) * coef_c  ->  V[img][off + pos*C + c]   (C % 64 == 0), split layout
+template <bool H1>
 __global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict__ f, int64_t n, int HW, int C, const float *__restrict__ coef,
                                                         char *__restrict__ V, int64_t ldv_bytes, int64_t off)
 {
@@ -128,7 +143,7 @@ __global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict_
         const int64_t k0 = off + (pos - im * HW) * C;
         for (int c = 2 * lane; c < C; c += 128) {
             const float2 t = *reinterpret_cast<const float2 *>(src + c);
-            split_store2(row, k0 + c, t.x * inv * coef[c], t.y * inv * coef[c + 1]);
+            v_store2<H1>(row, k0 + c, t.x * inv * coef[c], t.y * inv * coef[c + 1]);
         }
     }
 }
@@ -148,6 +163,66 @@ __global__ void __launch_bounds__(256) image_part_kernel(const T *__restrict__ i
         const int64_t im = e / D;
         const int64_t k = e - im * D;
         split_store2(V + im * ldv_bytes, off + k, load_pixel(img + e, lut) * sc, load_pixel(img + e + 1, lut) * sc);
+    }
+}
+
+// image part of a search row: x_k / sqrt(D) * 2^14 = hi + lo, stored as three segments of Dp halves (Dp = D rounded up to 64, zero
+// padded) so that a plain fp16 dot of a query row and a bank row yields hi_q hi_n + hi_q lo_n + lo_q hi_n:
+//   query rows  [hi | hi | lo]      bank rows  [hi | lo | hi]        (lo_seg = 2 for queries, 1 for bank rows)
+// (8-bit images take only 256 values, so rounding x to ONE half gives a systematic ~1e-4 error in the L2 term; the LPIPS values do not)
+template <typename T>
+__global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict__ img, int64_t n, int64_t D, int64_t Dp, float inv_sqrt_d, char *__restrict__ V,
+                                                            int64_t ldv_bytes, int64_t off, int lo_seg)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
+    __syncthreads();
+    const int64_t total = n * Dp;
+    const float sc = inv_sqrt_d * kVScale;
+    const int hi2_seg = 3 - lo_seg;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t im = i / Dp;
+        const int64_t k = i - im * Dp;
+        const float v = k < D ? load_pixel(img + im * D + k, lut) * sc : 0.0f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16 *row = reinterpret_cast<_Float16 *>(V + im * ldv_bytes) + off;
+        row[k] = hi;
+        row[hi2_seg * Dp + k] = hi;
+        row[lo_seg * Dp + k] = lo;
+    }
+}
+
+// |row|^2 of a search row (unscaled): sum over the LPIPS halves of h^2 + sum over the image part of (hi + lo)^2
+__global__ void __launch_bounds__(256) row_sqnorm_h1_kernel(const char *__restrict__ V, int64_t n, int64_t K_lp, int64_t Dp, int lo_seg, float *__restrict__ out)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    __shared__ double red[256];
+    const int64_t K1 = K_lp + 3 * Dp;
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const _Float16 *row = reinterpret_cast<const _Float16 *>(V + r * K1 * 2);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        for (int64_t k = (int64_t)threadIdx.x * 8; k < K_lp + Dp; k += 256 * 8) {
+            const h8 h = *reinterpret_cast<const h8 *>(row + k);
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+            if (k >= K_lp) {
+                const h8 l = *reinterpret_cast<const h8 *>(row + k + lo_seg * Dp);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
+            }
+            s0 = fmaf(v[0], v[0], s0); s1 = fmaf(v[1], v[1], s1); s2 = fmaf(v[2], v[2], s2); s3 = fmaf(v[3], v[3], s3);
+            s0 = fmaf(v[4], v[4], s0); s1 = fmaf(v[5], v[5], s1); s2 = fmaf(v[6], v[6], s2); s3 = fmaf(v[7], v[7], s3);
+        }
+        red[threadIdx.x] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out[r] = (float)(red[0] / ((double)kVScale * (double)kVScale));
+        __syncthreads();
     }
 }
 
@@ -294,36 +369,71 @@ __global__ void __launch_bounds__(256) maxpool2_split_kernel(const char *__restr
     }
 }
 
-// lpips_tap_kernel for split-layout activations (values carry the factor kVggAct, which cancels in the normalisation)
-__global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__restrict__ f, int64_t n, int HW, int C, const float *__restrict__ coef,
+// lpips_tap_kernel for split-layout activations (values carry the factor kVggAct, which cancels in the normalisation).
+// A lane owns 8 consecutive channels (16 B of hi halves + 16 B of lo halves); C / 8 lanes share a position, so a wave covers
+// 512 / C positions per pass with 2 KiB of contiguous reads and C * 2 (or 4) bytes of contiguous writes per position.
+template <bool H1, int C>
+__global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__restrict__ f, int64_t n, int HW, const float *__restrict__ coef,
                                                               char *__restrict__ V, int64_t ldv_bytes, int64_t off)
 {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int G = C / 8;            // lanes per position
+    constexpr int P = 64 / G;           // positions per wave and pass
     const int lane = threadIdx.x & 63;
+    const int cb = lane % G, pl = lane / G;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int64_t total = n * HW;
-    for (int64_t pos = wave; pos < total; pos += nwaves) {
-        const char *src = f + pos * C * 4;
+    float cf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cf[j] = coef[cb * 8 + j];
+    const int in_off = (cb >> 2) * 128 + (cb & 3) * 16;          // hi halves of channels 8 cb .. 8 cb + 7 (lo: + 64)
+    for (int64_t p0 = wave * P; p0 < total; p0 += nwaves * P) {
+        const int64_t pos = p0 + pl;
+        const bool live = pos < total;
+        float v[8];
         float ss = 0.0f;
-        for (int c = 2 * lane; c < C; c += 128) {
-            const char *q = src + (c >> 5) * 128 + (c & 31) * 2;
-            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
-            const float a = (float)hi[0] + (float)lo[0], b = (float)hi[1] + (float)lo[1];
-            ss = fmaf(a, a, ss); ss = fmaf(b, b, ss);
+        if (live) {
+            const char *src = f + pos * C * 4 + in_off;
+            const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] = (float)hi[j] + (float)lo[j]; ss = fmaf(v[j], v[j], ss); }
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        if (!live) continue;
         const float inv = kVScale / (sqrtf(ss) + 1e-10f * kVggAct);        // (A f) / (|A f| + A eps) = f / (|f| + eps)
         const int64_t im = pos / HW;
         char *row = V + im * ldv_bytes;
-        const int64_t k0 = off + (pos - im * HW) * C;
-        for (int c = 2 * lane; c < C; c += 128) {
-            const char *q = src + (c >> 5) * 128 + (c & 31) * 2;
-            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
-            const float a = (float)hi[0] + (float)lo[0], b = (float)hi[1] + (float)lo[1];
-            split_store2(row, k0 + c, a * inv * coef[c], b * inv * coef[c + 1]);
+        const int64_t k = off + (pos - im * HW) * C + cb * 8;
+        h8 oh, ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = v[j] * inv * cf[j];
+            oh[j] = (_Float16)t;
+            ol[j] = (_Float16)(t - (float)oh[j]);
         }
+        if constexpr (H1) {
+            *reinterpret_cast<h8 *>(row + k * 2) = oh;
+        } else {
+            char *dst = row + split_off(k);
+            *reinterpret_cast<h8 *>(dst) = oh;
+            *reinterpret_cast<h8 *>(dst + 64) = ol;
+        }
+    }
+}
+
+int stream_blocks(int64_t items);
+
+template <bool H1>
+void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, const float *coef, char *V, int64_t ldv, int64_t off)
+{
+    const dim3 grid((unsigned)stream_blocks(n * HW * (C / 8)));
+    switch (C) {
+    case 64: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
+    case 128: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
+    case 256: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
+    default: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
     }
 }
 
@@ -438,6 +548,120 @@ feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_no
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// feat_knn_h1_kernel: the same search on "search rows" (one half per value, gl_lpips_search_features_*): a plain fp16 GEMM,
+// one v_mfma_f32_16x16x32_f16 per product instead of three and half the operand bytes.
+// The 128 x 128 kernel above is fed from beyond L2 at ~19 B/clk/CU (the Infinity-Cache gather rate) and that, not the
+// matrix pipe, sets its time; so this one uses a 256 x 256 tile (bytes per MFMA halved): 8 waves as 2 (bank) x 4 (query),
+// each 128 bank rows x 64 queries = 8 x 4 tiles of 16 x 16; K slices of 64 halves (128 B per row, 64 KiB per slice for both
+// operands) double buffered in 128 KiB of LDS, one workgroup per CU.  Block order: strips of 4 bank tiles with the bank tile
+// fastest, so the 32 workgroups of an XCD cover 4 bank x 8 query tiles and share operand panels in its L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int GT = 256, GOPER = GT * FROW;
+
+__global__ void __launch_bounds__(512, 2)
+feat_knn_h1_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                   const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
+                   unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][bank 32 KiB | query 32 KiB]
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
+    int qt, nt;
+    {
+        constexpr int STRIP = 4;
+        const unsigned per_strip = (unsigned)STRIP * (unsigned)q_tiles;
+        const int strip = (int)(id / per_strip);
+        const unsigned r = id % per_strip;
+        const int width = n_tiles - strip * STRIP < STRIP ? n_tiles - strip * STRIP : STRIP;
+        nt = strip * STRIP + (int)(r % (unsigned)width);
+        qt = (int)(r / (unsigned)width);
+    }
+    const int64_t n0 = (int64_t)nt * GT, q0 = (int64_t)qt * GT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wq = wave & 3;
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int64_t row_bytes = K1 * 2;
+
+    // staging: a slice is 512 rows x 128 B = 64 pieces of 1 KiB (8 rows each); wave w loads bank pieces 4w..4w+3 and query pieces 4w..4w+3
+    const char *a_src[4], *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + rsub;
+        int64_t gn = n0 + r, gq = q0 + r;
+        if (gn >= n_rows) gn = n_rows - 1;      // clamped duplicates are masked in the epilogue
+        if (gq >= nq) gq = nq - 1;
+        a_src[i] = bank + gn * row_bytes + (slot ^ (r & 7)) * 16;
+        b_src[i] = query + gq * row_bytes + (slot ^ (r & 7)) * 16;
+    }
+    auto stage = [&](int64_t kt, char *buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl_glds16(a_src[i] + kt * FROW, buf + (wave * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + kt * FROW, buf + GOPER + (wave * 4 + i) * 1024);
+    };
+
+    v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    const int64_t nk = K1 / 64;
+    stage(0, smem);
+    const int frow = lane & 15, fk = lane >> 4;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        const char *cur = smem + (kt & 1) * 2 * GOPER;
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * GOPER);
+        const char *la = cur + (wn * 128) * FROW;
+        const char *lb = cur + GOPER + (wq * 64) * FROW;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            v8h a[8], b[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = i * 16 + frow;
+                a[i] = *reinterpret_cast<const v8h *>(la + r * FROW + (((4 * ks + fk) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = j * 16 + frow;
+                b[j] = *reinterpret_cast<const v8h *>(lb + r * FROW + (((4 * ks + fk) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: C tile 16x16: column (query) = lane & 15, row (bank) = 4 * (lane >> 4) + reg
+    const float inv_s2 = 1.0f / (kVScale * kVScale);
+    const int64_t nbase = n0 + wn * 128 + fk * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t q = q0 + wq * 64 + j * 16 + frow;
+        const float qn = q < nq ? query_norm[q] : 0.0f;
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = nbase + i * 16 + r;
+                const float bn = n < n_rows ? bank_norm[n] : 0.0f;
+                const float d = fmaxf(fmaf(-2.0f * inv_s2, acc[i][j][r], __fadd_rn(qn, bn)), 0.0f);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
+                if (n < n_rows && key < best) best = key;
+            }
+        unsigned long long o = __shfl_xor(best, 16, 64);
+        best = o < best ? o : best;
+        o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+    }
+}
+
 }  // namespace
 
 struct gl_lpips {
@@ -492,8 +716,9 @@ int stream_blocks(int64_t items)
 }
 
 template <typename T>
-int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
+int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, void *V_dev, float *norms_dev, int fmt)
 {
+    // fmt 0: split rows of K values (4 K bytes);  1 / 2: search rows for queries / bank rows (K_lp + 3 Dp halves)
     GL_REQUIRE(l && n >= 0, "gl_lpips_features: bad argument");
     GL_REQUIRE(H >= 16 && W >= 16 && H % 16 == 0 && W % 16 == 0, "gl_lpips_features: H, W must be multiples of 16 (four 2x2 pools), got %dx%d", H, W);
     for (int i = 0; i < kNumConv; ++i)
@@ -512,6 +737,9 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
         for (int t = 0; t < 5; ++t) { K_lp += (int64_t)kTapC[t] * h * w; h /= 2; w /= 2; }
     }
     const int64_t K = K_lp + D;
+    const int64_t Dp = gl_ceil_div(D, 64) * 64;
+    const int64_t ldv = fmt ? (K_lp + 3 * Dp) * 2 : K * 4;        // bytes per row of V
+    const int lo_seg = fmt == 1 ? 2 : 1;
     // per-tap coefficients sqrt(0.2 * w_c / (h*w))
     {
         std::vector<float> coef;
@@ -526,7 +754,7 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
 
     for (int64_t i0 = 0; i0 < n; i0 += l->ws_imgs) {
         const int64_t m = (n - i0 < l->ws_imgs) ? n - i0 : l->ws_imgs;
-        float *Vc = V_dev + i0 * K;
+        char *Vc = reinterpret_cast<char *>(V_dev) + i0 * ldv;
         const bool h3 = l->precision == 1;
         if (h3)
             hipLaunchKernelGGL(vgg_input_split_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W,
@@ -563,12 +791,15 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             which ^= 1;
             if (kAfter[ci] >= 1) {
                 const int C = kCout[ci];
-                if (h3)
-                    hipLaunchKernelGGL(lpips_tap_split_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream,
-                                       reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, reinterpret_cast<char *>(Vc), K * 4, off);
+                const dim3 tg((unsigned)stream_blocks(m * h * w * 64));
+                if (h3 && fmt)
+                    launch_tap_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
+                else if (h3)
+                    launch_tap_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
+                else if (fmt)
+                    hipLaunchKernelGGL(lpips_tap_kernel<true>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
                 else
-                    hipLaunchKernelGGL(lpips_tap_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream, cur, m, h * w, C,
-                                       l->ws_coef + coef_off, reinterpret_cast<char *>(Vc), K * 4, off);
+                    hipLaunchKernelGGL(lpips_tap_kernel<false>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
                 GL_LAUNCH_CHECK();
                 off += (int64_t)C * h * w;
                 coef_off += C;
@@ -587,10 +818,17 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 h /= 2; w /= 2;
             }
         }
-        hipLaunchKernelGGL(image_part_kernel<T>, dim3((unsigned)stream_blocks(m * D)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D,
-                           (float)(1.0 / std::sqrt((double)D)), reinterpret_cast<char *>(Vc), K * 4, K_lp);
-        GL_LAUNCH_CHECK();
-        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, reinterpret_cast<const char *>(Vc), m, K, norms_dev + i0);
+        if (fmt) {
+            hipLaunchKernelGGL(image_part_h1_kernel<T>, dim3((unsigned)stream_blocks(m * Dp)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D, Dp,
+                               (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg);
+            GL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(row_sqnorm_h1_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, Vc, m, K_lp, Dp, lo_seg, norms_dev + i0);
+        } else {
+            hipLaunchKernelGGL(image_part_kernel<T>, dim3((unsigned)stream_blocks(m * D)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D,
+                               (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp);
+            GL_LAUNCH_CHECK();
+            hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, Vc, m, K, norms_dev + i0);
+        }
         GL_LAUNCH_CHECK();
     }
     return GL_OK;
@@ -712,12 +950,56 @@ int64_t gl_lpips_feature_dim(int H, int W)
 
 int gl_lpips_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
 {
-    return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V_dev, norms_dev);
+    return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V_dev, norms_dev, 0);
 }
 
 int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
 {
-    return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V_dev, norms_dev);
+    return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V_dev, norms_dev, 0);
+}
+
+int64_t gl_lpips_search_dim(int H, int W)
+{
+    const int64_t k = gl_lpips_feature_dim(H, W);
+    if (k < 0) return -1;
+    const int64_t D = 3ll * H * W;
+    return k - D + 3 * (gl_ceil_div(D, 64) * 64);
+}
+
+int gl_lpips_search_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev)
+{
+    GL_REQUIRE(role == 0 || role == 1, "gl_lpips_search_features: role must be 0 (query rows) or 1 (bank rows)");
+    return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V16_dev, norms_dev, 1 + role);
+}
+
+int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev)
+{
+    GL_REQUIRE(role == 0 || role == 1, "gl_lpips_search_features: role must be 0 (query rows) or 1 (bank rows)");
+    return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V16_dev, norms_dev, 1 + role);
+}
+
+int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
+                   const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev)
+{
+    GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K1 > 0 && K1 % 64 == 0, "gl_feat_knn_h1: bad sizes (K1 must be a multiple of 64)");
+    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn_h1: global index does not fit 32 bits");
+    if (n_rows == 0 || nq == 0) return GL_OK;
+    GL_REQUIRE(bank_V16_dev && bank_norm_dev && query_V16_dev && query_norm_dev && keys_dev, "gl_feat_knn_h1: NULL device pointer");
+    GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V16_dev) | reinterpret_cast<uintptr_t>(query_V16_dev)) & 15) == 0, "gl_feat_knn_h1: rows must be 16-byte aligned");
+    const int64_t q_tiles = gl_ceil_div(nq, GT), n_tiles = gl_ceil_div(n_rows, GT);
+    GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn_h1: grid too large");
+    static bool attr_set = false;
+    const int lds = 4 * GOPER;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
+    hipLaunchKernelGGL(feat_knn_h1_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev), bank_norm_dev, n_rows,
+                       index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
+                       (int)n_tiles);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
 }
 
 int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,

@@ -34,10 +34,13 @@ def _np(v):
 class FeatureBank:
     """V rows + |V|^2 of a set of images, resident in HBM (gl_lpips_features_*)."""
 
-    def __init__(self, ctx, V, norms, n, K, K_lp, index_base=0):
+    def __init__(self, ctx, V, norms, n, K, K_lp, index_base=0, role=None):
         self.ctx, self.V, self.norms, self.n, self.K, self.K_lp = ctx, V, norms, int(n), int(K), int(K_lp)
         self.index_base = int(index_base)
         self.kind = "feat"
+        # None: split rows (hi + lo halves of every value; any use).  'query' / 'bank': search rows (one half per LPIPS value,
+        # K = gl_lpips_search_dim halves), usable only as the two sides of feat_knn_keys
+        self.role = role
 
     def __len__(self):
         return self.n
@@ -51,6 +54,9 @@ class LpipsModel:
         self._handle = h
         self._loaded = False
         self._precision = 1
+        # rows attack() builds for the nearest-neighbour search: 'fp16' = search rows (gl_feat_knn_h1: one fp16 MFMA per
+        # product, 1.07 MB per 64x64 image), 'split' = hi + lo rows (gl_feat_knn: three MFMAs, 2.05 MB)
+        self.search_rows = os.environ.get("GANLEAKS_LPIPS_SEARCH", "fp16")
 
     def __del__(self):
         if getattr(self, "_handle", None) is not None:
@@ -102,8 +108,16 @@ class LpipsModel:
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_lpips_set_chunk(self._handle, int(images_per_pass)))
 
-    def features(self, images, index_base=0):
-        """images [n,3,H,W] (u8, or float in [-1,1]) -> FeatureBank."""
+    def search_role(self, role):
+        """role to pass to features() for attack()'s two operands under the current `search_rows` setting"""
+        if self.search_rows not in ("fp16", "split"):
+            raise ValueError("LpipsModel.search_rows must be 'fp16' or 'split', got %r" % (self.search_rows,))
+        return role if self.search_rows == "fp16" else None
+
+    def features(self, images, index_base=0, role=None):
+        """images [n,3,H,W] (u8, or float in [-1,1]) -> FeatureBank.  role None: split rows; 'query' / 'bank': search rows."""
+        if role not in (None, "query", "bank"):
+            raise ValueError("role must be None, 'query' or 'bank', got %r" % (role,))
         if not self._loaded:
             raise RuntimeError("LpipsModel: weights not loaded")
         ctx = self.ctx
@@ -115,23 +129,33 @@ class LpipsModel:
         if K < 0:
             raise ValueError("LPIPS path needs H and W to be multiples of 16, got %dx%d" % (H, W))
         rows = _to_device_rows(ctx, images)
-        V = ctx.empty((max(n, 1), K), np.float32)
+        if role is None:
+            V = ctx.empty((max(n, 1), K), np.float32)
+        else:
+            K1 = int(ctx.lib.gl_lpips_search_dim(H, W))
+            V = ctx.empty((max(n, 1), K1), np.float16)
         norms = ctx.empty((max(n, 1),), np.float32)
+        r = 0 if role == "query" else 1
         if rows.dtype == np.float32:
             u8, bad = encode_if_lattice(ctx, rows)
             if bad == 0:
                 rows = u8
         def run():
-            if rows.dtype == np.uint8:
-                check(ctx.lib.gl_lpips_features_u8(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+            u8 = rows.dtype == np.uint8
+            if role is None:
+                fn = ctx.lib.gl_lpips_features_u8 if u8 else ctx.lib.gl_lpips_features_f32
+                check(fn(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
             else:
-                check(ctx.lib.gl_lpips_features_f32(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+                fn = ctx.lib.gl_lpips_search_features_u8 if u8 else ctx.lib.gl_lpips_search_features_f32
+                check(fn(self._handle, _p(rows.ptr), n, H, W, r, _p(V.ptr), _p(norms.ptr)))
         run()
         if self._precision == 1 and ctx.h3_saturations() > 0:
             import warnings
             warnings.warn("split-fp16 VGG16 path saturated for these weights; falling back to fp32 MFMA products")
             self.set_precision(0)
             run()
+        if role is not None:
+            return FeatureBank(ctx, V, norms, n, K1, K - 3 * H * W, index_base, role)
         return FeatureBank(ctx, V, norms, n, K, K - 3 * H * W, index_base)
 
 
@@ -152,11 +176,15 @@ def feat_knn_keys(bank, queries, n_rows=None, keys=None):
     ctx = bank.ctx
     if queries.K != bank.K:
         raise ValueError("feature lengths differ: %d vs %d" % (queries.K, bank.K))
+    roles = (getattr(bank, "role", None), getattr(queries, "role", None))
+    if roles not in ((None, None), ("bank", "query")):
+        raise ValueError("feat_knn_keys needs two split FeatureBanks or search rows of roles ('bank', 'query'); got %r" % (roles,))
     n_rows = bank.n if n_rows is None else int(n_rows)
     if keys is None:
         keys = ctx.empty((max(queries.n, 1),), np.uint64)
         check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), queries.n))
-    check(ctx.lib.gl_feat_knn(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
+    fn = ctx.lib.gl_feat_knn_h1 if roles[0] else ctx.lib.gl_feat_knn
+    check(fn(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
                                   _p(queries.norms.ptr), queries.n, bank.K, _p(keys.ptr)))
     return keys
 
@@ -164,6 +192,8 @@ def feat_knn_keys(bank, queries, n_rows=None, keys=None):
 def rows_dist(a, g):
     """(lpips [b], l2 [b]) between FeatureBanks a (x_hat) and g (x_gt, 1 row or b rows)."""
     ctx = a.ctx
+    if getattr(a, "role", None) or getattr(g, "role", None):
+        raise ValueError("rows_dist needs split FeatureBanks (features(..., role=None))")
     lp = ctx.empty((max(a.n, 1),), np.float32)
     l2 = ctx.empty((max(a.n, 1),), np.float32)
     check(ctx.lib.gl_feat_rows_dist(ctx.handle, _p(a.V.ptr), a.n, _p(g.V.ptr), g.n, a.K, a.K_lp, _p(lp.ptr), _p(l2.ptr)))

@@ -225,6 +225,16 @@ int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int 
  * fp16 MFMAs per product on the hi/lo halves (fp32 accumulation). */
 int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
                     const float *query_norm_dev, int64_t nq, int64_t K, uint64_t *keys_dev);
+/* Search rows: the same V with ONE half per LPIPS value (V * 2^14 rounded once; measured effect on a distance <= 3e-7) and the image part kept
+ * as hi/lo halves in three segments (query rows [hi|hi|lo], bank rows [hi|lo|hi], each padded to a multiple of 64), so that a plain fp16 dot of a
+ * query row and a bank row is the split-fp16 product for the L2 term.  Row length gl_lpips_search_dim(H, W) halves (536 576 at 64 x 64 = 1.07 MB per
+ * image instead of 2.05 MB).  role: 0 = query rows, 1 = bank rows.  norms_dev [n] = |row|^2 of the values the rows actually hold. */
+int64_t gl_lpips_search_dim(int H, int W);
+int gl_lpips_search_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev);
+int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev);
+/* gl_feat_knn on search rows: same keys, one fp16 MFMA per product, 256 x 256 tiles.  K1 = gl_lpips_search_dim. */
+int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
+                   const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev);
 /* Loss('l2-lpips').forward: per row, out_lpips = LPIPS and out_l2 = mean((y-x)^2) between V_hat[i] and V_gt[b_gt == 1 ? 0 : i];
  * K_lp = K - 3 H W is the length of the LPIPS part of V */
 int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,

@@ -37,15 +37,21 @@ def _case(g, synth):
     return case["bank"], np.concatenate([case["pos"], case["neg"]])
 
 
+@pytest.mark.parametrize("search_rows", ["fp16", "split"])
 @pytest.mark.parametrize("precision", [1, 0])
 @pytest.mark.parametrize("name", ["lpips_res32", "lpips_res64"])
-def test_attack_l2_lpips_matches_reference(name, precision, gl, synth, model, golden_dir):
-    """precision 1 (default): VGG16 convolutions as split-fp16; 0: fp32 MFMA.  Same bound."""
+def test_attack_l2_lpips_matches_reference(name, precision, search_rows, gl, synth, model, golden_dir):
+    """precision 1 (default): VGG16 convolutions as split-fp16; 0: fp32 MFMA.  search_rows 'fp16' (default): one half per
+    LPIPS value + hi/lo image part, gl_feat_knn_h1; 'split': hi + lo of everything, gl_feat_knn.  Same bound for all four."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     bank, q = _case(g, synth)
     model.set_precision(precision)
-    dist, idx = gl.attack(q, bank, distance="l2-lpips", batch_size=int(g["batch_size"]), lpips=model)
-    model.set_precision(1)
+    model.search_rows = search_rows
+    try:
+        dist, idx = gl.attack(q, bank, distance="l2-lpips", batch_size=int(g["batch_size"]), lpips=model)
+    finally:
+        model.set_precision(1)
+        model.search_rows = "fp16"
     assert np.array_equal(idx, g["idx"])
     err = np.abs(dist.astype(np.float64) - g["dist"]).max()
     assert err < ATOL, err
@@ -95,14 +101,39 @@ def test_vs_fp64_oracle_ragged_and_shards(gl, synth, model, lin, oracle):
     od, oi, _ = lpips_oracle.knn_l2_lpips(sd, linl, bf, qf, 8)
     d, i = gl.attack(qf, bf, distance="l2-lpips", batch_size=8, lpips=model)
     assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
-    # shards
-    fq = model.features(q)
-    keys = None
-    for lo, hi in ((16, 32), (0, 16)):
-        keys = feat_knn_keys(model.features(bank[lo:hi], index_base=lo), fq, keys=keys)
-    ds, is_ = unpack_keys(gl.Context.get(), keys, fq.n, fq.K, "f32")
-    d0, i0 = gl.attack(q, bank, distance="l2-lpips", batch_size=8, lpips=model)
-    assert np.array_equal(is_, i0) and np.array_equal(ds, d0)
+    # shards, both row formats
+    for roles in ((None, None), ("bank", "query")):
+        fq = model.features(q, role=roles[1])
+        keys = None
+        for lo, hi in ((16, 32), (0, 16)):
+            keys = feat_knn_keys(model.features(bank[lo:hi], index_base=lo, role=roles[0]), fq, keys=keys)
+        ds, is_ = unpack_keys(gl.Context.get(), keys, fq.n, fq.K, "f32")
+        model.search_rows = "fp16" if roles[0] else "split"
+        try:
+            d0, i0 = gl.attack(q, bank, distance="l2-lpips", batch_size=8, lpips=model)
+        finally:
+            model.search_rows = "fp16"
+        assert np.array_equal(is_, i0) and np.array_equal(ds, d0)
+    with pytest.raises(ValueError):
+        feat_knn_keys(model.features(bank[:8]), model.features(q, role="query"))
+
+
+def test_search_rows_multi_tile(gl, synth, model):
+    """600 bank rows x 300 queries: several 256 x 256 tiles with ragged edges in both directions.  No CPU oracle at this size
+    (VGG16 in fp64 takes minutes); the split-row search, itself pinned to the oracle above, is the reference."""
+    case = synth.attack_case(97, 600, 150, 150, 32, sigma=20.0)
+    bank = case["bank"]
+    q = np.concatenate([case["pos"], case["neg"]])
+    out = {}
+    for rows in ("split", "fp16"):
+        model.search_rows = rows
+        try:
+            out[rows] = gl.attack(q, bank, distance="l2-lpips", batch_size=64, lpips=model)
+        finally:
+            model.search_rows = "fp16"
+    assert out["fp16"][1].max() < 576
+    assert np.array_equal(out["fp16"][1], out["split"][1])
+    assert np.abs(out["fp16"][0] - out["split"][0]).max() < 2e-6
 
 
 def test_fbb_main_default_distance_with_local_weights(tmp_path, monkeypatch, gl, synth, lin, model):
