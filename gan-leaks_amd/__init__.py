@@ -14,4 +14,4 @@ __version__ = "0.1.0"
 
 from . import synth  # noqa: F401
 from ._lib import Context, DeviceArray, GanLeaksError, build, device_count  # noqa: F401
-from .attack import Bank, attack, prepare_images  # noqa: F401
+from .attack import Bank, GeneratedBank, attack, prepare_images  # noqa: F401

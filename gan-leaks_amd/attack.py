@@ -116,6 +116,30 @@ class Bank:
         return self.n
 
 
+class GeneratedBank:
+    """a bank that is never materialised: rows [lo, hi) are generated on demand, `generator.generate_u8(z[lo:hi], **kwargs)`,
+    in the order the reference's generate branch would have written them as image_{i}.png (bank index = z index).
+    `index_base` is the global index of z[0] when z is one shard of the latents (shard.py)."""
+    kind = "generated"
+
+    def __init__(self, generator, z, index_base=0, **generate_kwargs):
+        if not hasattr(generator, "generate_u8"):
+            raise TypeError("generator must provide generate_u8(z, ...) -> u8 DeviceArray")
+        self.generator, self.z, self.index_base, self.kwargs = generator, z, int(index_base), generate_kwargs
+        self.ctx = generator.ctx
+
+    def __len__(self):
+        return len(self.z)
+
+    def rows(self, lo, hi):
+        return self.generator.generate_u8(self.z[lo:hi], **self.kwargs)
+
+
+def _budget_bytes():
+    import os
+    return int(float(os.environ.get("GANLEAKS_CHUNK_GB", "64")) * (1 << 30))
+
+
 def knn_keys(bank, queries, n_rows=None, keys=None):
     """launch the pairwise kernel: packed keys DeviceArray [Q] (uint64), min over bank rows [0, n_rows).
     u8 path: (S << 32) | global index; f32 path: (float_bits(dist) << 32) | global index.  Asynchronous."""
@@ -150,13 +174,68 @@ def unpack_keys(ctx, keys, nq, d, kind="u8"):
     return dist.numpy()[:nq], idx.numpy()[:nq]
 
 
-def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None):
+def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes):
+    """bank rows [0, n_rows) pass through HBM in chunks of at most `chunk_bytes` of prepared rows (int8 rows for 'l2', feature
+    rows for 'l2-lpips'); the packed keys accumulate the minimum across chunks (atomicMin), so the result is the one the
+    resident form gives.  `bank` is a GeneratedBank or a host array / DeviceArray of images."""
+    generated = getattr(bank, "kind", None) == "generated"
+    base = bank.index_base if generated else 0
+
+    def rows(lo, hi):
+        if generated:
+            return bank.rows(lo, hi)
+        return bank.view((hi - lo,) + tuple(bank.shape[1:]), offset_bytes=lo * (bank.nbytes // max(len(bank), 1))) if isinstance(bank, DeviceArray) else bank[lo:hi]
+
+    def finish(keys, nq, d, kind):
+        if keys is None:                 # a shard without rows still takes part in the reduction
+            keys = ctx.empty((max(nq, 1),), np.uint64)
+            check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), nq))
+        if reduce_fn is not None:
+            keys = reduce_fn(keys)
+        return unpack_keys(ctx, keys, nq, d, kind)
+
+    if distance == "l2-lpips":
+        from . import lpips as _lp
+        fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=model.search_role("query"))
+        b_role = "bank" if getattr(fq, "role", None) else None
+        step = max(1, int(chunk_bytes // (fq.K * (2 if fq.role else 4))))
+        keys = None
+        for lo in range(0, n_rows, step):
+            hi = min(lo + step, n_rows)
+            keys = _lp.feat_knn_keys(model.features(rows(lo, hi), index_base=base + lo, role=b_role), fq, keys=keys)
+            ctx.sync()                   # the chunk's rows are released when the temporaries go
+        return finish(keys, fq.n, fq.K, "f32")
+
+    # 'l2': every chunk must take the same arithmetic path.  Exact integers unless the queries or some chunk are off the 8-bit lattice;
+    # then everything is redone on the fixed-order fp32 path (what the resident form does for such inputs).
+    fq = queries if isinstance(queries, Bank) else Bank.from_images(queries, ctx, keep_u8=True)
+    for force in (("u8", "f32") if fq.kind == "u8" else ("f32",)):
+        q_side = fq if fq.kind == force else fq.as_f32()
+        step = max(1, int(chunk_bytes // ((2 if force == "u8" else 4) * fq.d)))
+        keys, ok = None, True
+        for lo in range(0, n_rows, step):
+            hi = min(lo + step, n_rows)
+            try:
+                b = Bank.from_images(rows(lo, hi), ctx, index_base=base + lo, force_kind=force)
+            except ValueError:           # an off-lattice chunk
+                ok = False
+                break
+            keys, _, _ = knn_keys(b, q_side, keys=keys)
+            ctx.sync()
+        if ok:
+            return finish(keys, fq.n, fq.d, force)
+    raise AssertionError("unreachable")
+
+
+def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None, chunk_bytes=None):
     """nearest bank sample of every query.
 
     queries : [Q,C,H,W] images, u8 or float; numpy / torch / DeviceArray / Bank / FeatureBank
     bank    : same, or a prepared `Bank` / `FeatureBank` (then `batch_size` truncation applies to len(bank)
               unless the bank is a shard -- index_base > 0 or reduce_fn given: shards are cut after the
-              global truncation, see shard.py)
+              global truncation, see shard.py), or a `GeneratedBank(generator, z)` whose rows are generated,
+              searched and dropped chunk by chunk.  Unprepared banks whose prepared rows would exceed `chunk_bytes`
+              (default $GANLEAKS_CHUNK_GB = 64 GiB) are streamed through HBM the same way.
     distance: 'l2' (attack_models/utils.py:161-164) or 'l2-lpips' = 0.2*LPIPS + L2, the reference's fbb
               distance (attack_models/fbb.py:148, utils.py:166-176).  `lpips` is the LpipsModel to use
               (default: lpips.default_model(), weights from local files).
@@ -167,11 +246,12 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
     if distance not in ("l2", "l2-lpips"):
         raise ValueError("distance must be 'l2' or 'l2-lpips', got %r" % (distance,))
     prepared = isinstance(bank, Bank) or getattr(bank, "kind", None) == "feat"
-    if prepared:
+    generated = getattr(bank, "kind", None) == "generated"
+    if prepared or generated:
         ctx = bank.ctx
-        n_rows = bank.n
+        n_rows = len(bank)
         if reduce_fn is None and bank.index_base == 0:
-            n_rows = (bank.n // int(batch_size)) * int(batch_size)
+            n_rows = (n_rows // int(batch_size)) * int(batch_size)
     else:
         ctx = ctx or Context.get()
         n_total = len(bank)
@@ -179,6 +259,24 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
     if n_rows == 0 and reduce_fn is None:
         # the reference dies in torch.cat([]) (fbb.py:83) with ValueError
         raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
+    model = None
+    if distance == "l2-lpips":
+        from . import lpips as _lp
+        model = lpips or _lp.default_model()
+    if not prepared:
+        chunk_bytes = _budget_bytes() if chunk_bytes is None else int(chunk_bytes)
+        if generated:
+            need = chunk_bytes + 1
+        else:
+            per_img = int(np.prod(tuple(bank.shape[1:]), dtype=np.int64)) if len(bank) else 0
+            if distance == "l2-lpips" and len(bank):
+                per_img = 2 * int(ctx.lib.gl_lpips_search_dim(int(bank.shape[2]), int(bank.shape[3]))) if model.search_rows == "fp16" \
+                    else 4 * int(ctx.lib.gl_lpips_feature_dim(int(bank.shape[2]), int(bank.shape[3])))
+            else:
+                per_img *= 2             # u8 codes + int8 rows
+            need = per_img * n_rows
+        if need > chunk_bytes:
+            return _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes)
     if not prepared and n_rows > 0:
         if isinstance(bank, DeviceArray):
             bank = bank.view((n_rows,) + tuple(bank.shape[1:]))
@@ -186,8 +284,6 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
             bank = bank[:n_rows]
 
     if distance == "l2-lpips":
-        from . import lpips as _lp
-        model = lpips or _lp.default_model()
         fb = bank if prepared else model.features(bank, role=model.search_role("bank"))
         q_role = "query" if getattr(fb, "role", None) else None          # queries follow the bank's row format
         fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=q_role)

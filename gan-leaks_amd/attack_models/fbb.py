@@ -136,17 +136,17 @@ def main(args):
         n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
         if n_rows == 0:
             raise ValueError("torch.cat(): expected a non-empty list of Tensors")
-        if distance == "l2-lpips":
-            bank = custom_loss.lpips_model.features(syn_imgs[:n_rows], role=custom_loss.lpips_model.search_role("bank"))
-        else:
-            bank = Bank.from_images(syn_imgs[:n_rows])
-
-        pos_d, pos_i = attack(pos_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
+        # both query sets go through ONE pass over the bank (the reference loops over it per query, fbb.py:156-168): the bank's
+        # prepared rows -- int8 rows or VGG16/LPIPS feature rows -- are built once, and streamed through HBM in chunks when
+        # they would not fit (ganleaks_amd.attack, $GANLEAKS_CHUNK_GB)
+        n_pos = len(pos_query_imgs)
+        all_d, all_i = attack(np.concatenate([pos_query_imgs, neg_query_imgs]), syn_imgs, distance=distance, batch_size=args.BATCH_SIZE,
+                              lpips=custom_loss.lpips_model)
+        pos_d, pos_i, neg_d, neg_i = all_d[:n_pos], all_i[:n_pos], all_d[n_pos:], all_i[n_pos:]
         pos_loss = pos_d.astype(np.float64).reshape(-1, 1)          # python floats -> float64 [Q,1] (fbb.py:160)
         plt_pos_idx = pos_i.reshape(-1, 1)
         save_files(save_dir, ['pos_loss', 'pos_idx'], [pos_loss, np.arange(len(pos_loss)).reshape(-1, 1)])
 
-        neg_d, neg_i = attack(neg_query_imgs, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
         neg_loss = neg_d.astype(np.float64).reshape(-1, 1)
         plt_neg_idx = neg_i.reshape(-1, 1)
         # the reference writes arange(len(pos_loss)) here as well (fbb.py:171): kept
