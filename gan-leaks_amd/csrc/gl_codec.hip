@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(kThreads) l2_prepare_kernel(const uint8_t *__r
     for (int64_t r = wave; r < count; r += nwaves) {
         const uint8_t *src = rows + r * d;
         int8_t *dst = out + r * stride;
-        int acc = 0;
+        int acc = 0;                       // sum (u-128)^2 <= 16384 d < 2^32: read as unsigned when d > 131071
         if (vec) {
             for (int64_t k = (int64_t)lane * 16; k < stride; k += 64 * 16) {
                 uint4 v = make_uint4(0, 0, 0, 0);
@@ -132,9 +132,10 @@ __global__ void __launch_bounds__(kThreads) l2_prepare_kernel(const uint8_t *__r
                 dst[k] = (int8_t)b;
             }
         }
+        unsigned total = (unsigned)acc;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) norms[r] = acc;
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o, 64);
+        if (lane == 0) norms[r] = (int32_t)total;
     }
 }
 
@@ -164,21 +165,21 @@ __global__ void __launch_bounds__(kThreads) l2_rows_u8_kernel(const uint8_t *__r
                 saa += a * a; sbb += c * c; sab += a * c;
             }
         }
-        unsigned s = saa + sbb - 2u * sab;
+        long long s = (long long)saa + (long long)sbb - 2ll * (long long)sab;   // per-lane parts fit 32 unsigned bits (d / 64 values each)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) out[r] = (float)((double)s * scale);
     }
 }
 
-__global__ void __launch_bounds__(kThreads) keys_unpack_kernel(const uint64_t *__restrict__ keys, int64_t nq, double scale,
+__global__ void __launch_bounds__(kThreads) keys_unpack_kernel(const uint64_t *__restrict__ keys, int64_t nq, double scale, int shift,
                                                                float *__restrict__ dist, int64_t *__restrict__ idx)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const uint64_t k = keys[i];
-    dist[i] = (float)((double)(k >> 32) * scale);   // fl32(S * 4/(255^2 D)), same expression as the oracle
-    idx[i] = (int64_t)(k & 0xFFFFFFFFull);
+    dist[i] = (float)((double)(k >> shift) * scale);   // fl32(S * 4/(255^2 D)), same expression as the oracle
+    idx[i] = (int64_t)(k & ((1ull << shift) - 1ull));
 }
 
 }  // namespace
@@ -227,7 +228,7 @@ int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_
 {
     GL_REQUIRE(ctx && count >= 0 && d > 0, "gl_l2_prepare: bad ctx/count/d");
     // sum (u-128)^2 <= 128^2 * d must fit int32 together with the cross term (see gl_l2knn.hip)
-    GL_REQUIRE(d <= 32768, "gl_l2_prepare: d=%lld exceeds the int32-exact limit 32768", (long long)d);
+    GL_REQUIRE(d <= GL_L2_MAX_D, "gl_l2_prepare: d=%lld exceeds the exact-integer limit %lld", (long long)d, (long long)GL_L2_MAX_D);
     if (count == 0) return GL_OK;
     GL_REQUIRE(rows_u8_dev && rows_i8_dev && norms_dev, "gl_l2_prepare: NULL device pointer");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(rows_i8_dev) & 15) == 0, "gl_l2_prepare: rows_i8_dev must be 16-byte aligned");
@@ -243,7 +244,7 @@ int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_
 
 int gl_l2_rows_u8(gl_ctx *ctx, const uint8_t *x_hat_u8_dev, int64_t b, const uint8_t *x_gt_u8_dev, int64_t b_gt, int64_t d, float *out_dev)
 {
-    GL_REQUIRE(ctx && b >= 0 && d > 0 && d <= 66051, "gl_l2_rows_u8: bad ctx/b/d");
+    GL_REQUIRE(ctx && b >= 0 && d > 0 && d <= GL_L2_MAX_D, "gl_l2_rows_u8: bad ctx/b/d");
     GL_REQUIRE(b_gt == 1 || b_gt == b, "gl_l2_rows_u8: x_gt must hold 1 row or %lld rows (broadcast rule of utils.py:163), got %lld", (long long)b,
                (long long)b_gt);
     if (b == 0) return GL_OK;
@@ -271,7 +272,7 @@ int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d,
     if (nq == 0) return GL_OK;
     GL_REQUIRE(keys_dev && dist_dev && idx_dev, "gl_keys_unpack: NULL device pointer");
     const double scale = 4.0 / (65025.0 * (double)d);
-    hipLaunchKernelGGL(keys_unpack_kernel, dim3((int)gl_ceil_div(nq, kThreads)), dim3(kThreads), 0, ctx->stream, keys_dev, nq, scale, dist_dev, idx_dev);
+    hipLaunchKernelGGL(keys_unpack_kernel, dim3((int)gl_ceil_div(nq, kThreads)), dim3(kThreads), 0, ctx->stream, keys_dev, nq, scale, gl_l2_key_shift(d), dist_dev, idx_dev);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -62,6 +62,17 @@ void gl_set_error(const char *fmt, ...);
 
 static inline int64_t gl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// exact-integer L2 path: S = sum_k (u_q - u_n)^2 <= 65025 d, packed as key = S << shift | global index.  The key stays below 2^63
+// because the cross-GPU minimum runs on the int64 view of the keys; shift is 32 for d <= 33025 (everything up to 3 x 104 x 104)
+// and shrinks by one bit per doubling of d beyond that (29 at 3 x 256 x 256, leaving 2^29 bank rows).
+constexpr int64_t GL_L2_MAX_D = 262143;          // row norms sum (u-128)^2 <= 16384 d must fit 32 unsigned bits
+static inline int gl_l2_key_shift(int64_t d)
+{
+    const unsigned long long smax = 65025ull * (unsigned long long)d;
+    const int bits = 64 - __builtin_clzll(smax);
+    return 63 - bits > 32 ? 32 : 63 - bits;
+}
+
 // XCD-aware block id remap (8 XCDs, blocks are dealt round-robin): gives every XCD a contiguous
 // chunk of the logical grid so blocks sharing an operand panel share an L2.  Bijective for any nwg.
 __device__ __forceinline__ unsigned gl_xcd_remap(unsigned bid, unsigned nwg)

@@ -4,8 +4,12 @@
 // Arithmetic: images live on the 8-bit lattice, so with a = u_bank-128, b = u_query-128 (int8)
 //     S(q,n) = sum_k (b_k - a_k)^2 = |a_n|^2 + |b_q|^2 - 2 * sum_k a_nk b_qk
 // is computed EXACTLY: the cross term on the int8 matrix cores (v_mfma_i32_16x16x64_i8, int32
-// accumulate), the norms precomputed by gl_l2_prepare.  Bounds for d <= 32768: |cross| <= 2^14 d,
-// |norm - 2 cross| <= 3 * 2^14 d < 2^31, 0 <= S <= 255^2 d < 2^31.
+// accumulate), the norms precomputed by gl_l2_prepare.  Ranges: 0 <= S <= 255^2 d.
+//   d <= 66051 (S < 2^32): norms, cross term and S are evaluated modulo 2^32 (two's-complement wrap-around of the int32
+//     accumulators is harmless), which is exact because the true S fits 32 unsigned bits;
+//   d <= 262143 (BIG = true): the int32 accumulators are flushed into 64-bit totals every 64 KiB of K (|cross| <= 2^30 per
+//     segment), S = |a|^2 + |b|^2 - 2 cross in 64 bits.
+// key = S << gl_l2_key_shift(d) | global index (shift 32 up to d = 33025).
 //
 // Tiling (v1): 128 bank rows x 128 queries per workgroup, 4 waves as 2 x 2, each wave 64 x 64 =
 // 4 x 4 MFMA tiles; K streamed in 128-byte slices, double buffered in LDS (64 KiB -> 2 WG/CU),
@@ -44,11 +48,13 @@ __device__ __forceinline__ void stage_operand(const int8_t *__restrict__ base, i
     }
 }
 
+template <bool BIG>
 __global__ void __launch_bounds__(THREADS, 2)
 l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                  const int8_t *__restrict__ query, const int32_t *__restrict__ query_norm, int64_t nq, int64_t stride,
-                 unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+                 unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, int shift)
 {
+    constexpr int FLUSH = 512;                        // slices per 64-bit flush (BIG): 64 KiB of K
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][bank 16 KiB | query 16 KiB]
 
     const unsigned nwg = (unsigned)q_tiles * (unsigned)n_tiles;
@@ -67,6 +73,17 @@ l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ ba
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+    long long tot[BIG ? 4 : 1][BIG ? 4 : 1][4] = {};
+    auto flush = [&]() {
+        if constexpr (BIG) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { tot[i][j][r] += (long long)acc[i][j][r]; acc[i][j][r] = 0; }
+        }
+    };
 
     const int nk = (int)(stride / TILE_K);
     stage_operand(bank, n0, n_rows, stride, 0, smem, wave, lane);
@@ -101,7 +118,9 @@ l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ ba
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (BIG && (kt % FLUSH) == FLUSH - 1) flush();
     }
+    flush();
 
     // ---- epilogue.  C layout of the 16x16 tile: column (query) = lane & 15, row (bank) = (lane>>4)*4 + reg.
     const int64_t nbase = n0 + wn * 64 + fk * 4;
@@ -123,8 +142,10 @@ l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ ba
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t n = nbase + i * 16 + r;
-                const int s = bn[i][r] + qn - 2 * acc[i][j][r];
-                const unsigned long long key = ((unsigned long long)(unsigned)s << 32) | (unsigned long long)(index_base + n);
+                unsigned long long s;
+                if constexpr (BIG) s = (unsigned long long)((long long)(unsigned)bn[i][r] + (long long)(unsigned)qn - 2ll * tot[i][j][r]);
+                else s = (unsigned)bn[i][r] + (unsigned)qn - 2u * (unsigned)acc[i][j][r];       // exact modulo 2^32, and S < 2^32
+                const unsigned long long key = (s << shift) | (unsigned long long)(index_base + n);
                 if (n < n_rows && key < best) best = key;
             }
         // the other three k-groups of lanes hold other bank rows of the same query
@@ -144,9 +165,11 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
                  const int8_t *query_i8_dev, const int32_t *query_norm_dev, int64_t nq, int64_t d, uint64_t *keys_dev)
 {
     GL_REQUIRE(ctx, "gl_l2_knn_i8: NULL ctx");
-    GL_REQUIRE(n_rows >= 0 && nq >= 0 && d > 0 && d <= 32768, "gl_l2_knn_i8: bad sizes n_rows=%lld nq=%lld d=%lld", (long long)n_rows,
-               (long long)nq, (long long)d);
-    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_l2_knn_i8: global index does not fit 32 bits");
+    GL_REQUIRE(n_rows >= 0 && nq >= 0 && d > 0 && d <= GL_L2_MAX_D, "gl_l2_knn_i8: bad sizes n_rows=%lld nq=%lld d=%lld (d <= %lld)", (long long)n_rows,
+               (long long)nq, (long long)d, (long long)GL_L2_MAX_D);
+    const int shift = gl_l2_key_shift(d);
+    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= (1ll << shift), "gl_l2_knn_i8: global index does not fit the %d index bits of a key at d=%lld", shift,
+               (long long)d);
     if (n_rows == 0 || nq == 0) return GL_OK;
     GL_REQUIRE(bank_i8_dev && bank_norm_dev && query_i8_dev && query_norm_dev && keys_dev, "gl_l2_knn_i8: NULL device pointer");
     GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_i8_dev) | reinterpret_cast<uintptr_t>(query_i8_dev)) & 15) == 0,
@@ -157,13 +180,15 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
     static bool attr_set = false;
     const int lds = 4 * OPER_BYTES;
     if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     gl_prof_scope prof_(ctx, GL_PROF_L2_KNN);
-    hipLaunchKernelGGL(l2_knn_i8_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(THREADS), lds, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows,
+    auto kern = d > 66051 ? l2_knn_i8_kernel<true> : l2_knn_i8_kernel<false>;      // 65025 * 66051 < 2^32
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q_tiles * n_tiles)), dim3(THREADS), lds, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows,
                        index_base, query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
-                       (int)n_tiles);
+                       (int)n_tiles, shift);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -99,12 +99,16 @@ int gl_quantize_f32(gl_ctx *ctx, const float *x_dev, int64_t count, int mode, ui
 /* bytes one prepared row occupies: D rounded up to the kernel's K tile */
 int64_t gl_l2_row_stride(int64_t d);
 /* u8 rows -> biased int8 rows (u-128, zero padded to gl_l2_row_stride(d)) and per-row sum (u-128)^2.
- * rows_i8_dev: [count][gl_l2_row_stride(d)] bytes; norms_dev: [count] int32. */
+ * rows_i8_dev: [count][gl_l2_row_stride(d)] bytes; norms_dev: [count] int32 (the bit pattern of an unsigned value when d > 131071).
+ * d <= 262143 (3 x 256 x 256 = 196608 fits). */
 int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_t d, int8_t *rows_i8_dev, int32_t *norms_dev);
 /* keys[q] = UINT64_MAX */
 int gl_keys_init(gl_ctx *ctx, uint64_t *keys_dev, int64_t nq);
-/* keys[q] = min(keys[q], (S(q,n) << 32) | (index_base + n)) over n in [0, n_rows):
- *   S = sum_k (uq_k - ub_k)^2, exact in int32.   Replaces the loop body + torch.min of custom_knn
+/* keys[q] = min(keys[q], (S(q,n) << shift) | (index_base + n)) over n in [0, n_rows):
+ *   S = sum_k (uq_k - ub_k)^2, exact integers (d <= 66051: modulo 2^32 with S < 2^32; up to d = 262143: int32 segments of 64 KiB of K
+ *   summed in 64 bits).  shift = 32 for d <= 33025 and one bit less per doubling of d beyond (31 at 3x128x128, 29 at 3x256x256) so that
+ *   keys stay below 2^63 for the int64 all-reduce(min); index_base + n_rows <= 2^shift.  gl_keys_unpack derives the same shift from d.
+ *   Replaces the loop body + torch.min of custom_knn
  *   (attack_models/fbb.py:77-86) with Loss('l2') (attack_models/utils.py:163,169,176) for the whole
  *   query set at once.  The caller applies the BATCH_SIZE truncation (fbb.py:77) by passing
  *   n_rows = n_eff.  index_base is the global index of bank row 0 (bank shards). */

@@ -131,6 +131,45 @@ def test_extreme_values_int32_exact(gl, coracle):
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
 
 
+@pytest.mark.parametrize("shape", [(3, 128, 128), (3, 256, 256), (262143,)])
+def test_large_images_exact(shape, gl, coracle):
+    """d > 32768: S no longer fits 31 bits.  3x128x128 runs modulo 2^32 (S < 2^32, key shift 31); 3x256x256 and the largest
+    supported d flush the int32 accumulators into 64-bit totals every 64 KiB of K (key shift 29).  All-0 against all-255 rows
+    give the largest S = 255^2 d."""
+    from ganleaks_amd.attack import Bank, knn_keys, unpack_keys
+    from ganleaks_amd.attack_models.utils import Loss
+    rng = np.random.default_rng(shape[-1])
+    bank = rng.integers(0, 256, size=(70,) + shape, dtype=np.uint8)
+    bank[3] = 0
+    bank[5] = 255
+    q = np.stack([np.full(shape, 255, np.uint8), np.zeros(shape, np.uint8), bank[40], rng.integers(0, 256, size=shape, dtype=np.uint8),
+                  rng.integers(100, 140, size=shape, dtype=np.uint8)])
+    dist, idx = gl.attack(q, bank, batch_size=32)
+    od, oi, ssd = coracle.knn_l2_u8(bank, q, 32)
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    assert idx[:3].tolist() == [5, 3, 40] and dist[:3].tolist() == [0, 0, 0]
+    # the far extreme: only rows of the opposite colour in the bank
+    d2, i2 = gl.attack(q[:2], np.zeros((16,) + shape, np.uint8), batch_size=16)
+    assert i2.tolist() == [0, 0] and d2[0] == np.float32(4.0) and d2[1] == 0
+    # Loss('l2').forward rows (gl_l2_rows_u8) at this d
+    v = Loss("l2")(bank[:8], q[:1])
+    ref = (coracle.ssd_row_u8(bank[:8], q[0]).astype(np.float64) * (4.0 / (65025.0 * q[0].size))).astype(np.float32)
+    assert np.array_equal(np.asarray(v, np.float32), ref)
+    # shards carry global indices through the narrower index field
+    ctx = gl.Context.get()
+    qb = Bank.from_images(q, ctx)
+    keys = None
+    for lo, hi in ((32, 64), (0, 32)):
+        keys, _, _ = knn_keys(Bank.from_images(bank[lo:hi], ctx, index_base=lo), qb, keys=keys)
+    d3, i3 = unpack_keys(ctx, keys, qb.n, qb.d)
+    assert np.array_equal(i3, oi) and np.array_equal(d3, od)
+    if shape == (3, 256, 256):
+        with pytest.raises(gl.GanLeaksError):
+            knn_keys(Bank.from_images(bank[:32], ctx, index_base=(1 << 29) - 8), qb)
+    with pytest.raises(gl.GanLeaksError):
+        Bank.from_images(np.zeros((2, 262144), np.uint8), ctx)
+
+
 def test_shard_invariance(gl, synth, coracle):
     """any split of the bank into index-based shards gives bit-identical (dist, idx)"""
     from ganleaks_amd.attack import Bank, knn_keys, unpack_keys
