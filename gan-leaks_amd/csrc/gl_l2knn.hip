@@ -20,6 +20,7 @@
 // one 64-bit atomicMin per (query, wave) on key = S << 32 | global_index  -- smallest index wins
 // ties, as torch.min does (fbb.py:86), independent of tile / shard order.
 #include "gl_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -157,6 +158,113 @@ l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ ba
     }
 }
 
+// 256 bank rows x 256 queries per workgroup: half the operand bytes per MFMA of the 128 x 128 tile.  The bank and the queries
+// are streamed from beyond L2 (a tile's two panels are 2 x 256 x d bytes; the co-resident tiles of an XCD cycle through more
+// panels than its 4 MiB L2 holds), and with the int8 matrix rate twice the fp16 one that stream, not the matrix pipe, sets the
+// time of the small tile.  8 waves as 2 (bank) x 4 (query), each 128 x 64 = 8 x 4 MFMA tiles; 128-byte K slices double buffered
+// in 128 KiB of LDS (one workgroup per CU); strips of 4 bank tiles so the 32 workgroups of an XCD cover 4 x 8 tiles.
+constexpr int BT = 256, BOPER = BT * TILE_K;
+
+__global__ void __launch_bounds__(512, 2)
+l2_knn_i8_256_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                     const int8_t *__restrict__ query, const int32_t *__restrict__ query_norm, int64_t nq, int64_t stride,
+                     unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, int shift)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][bank 32 KiB | query 32 KiB]
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
+    int qt, nt;
+    {
+        constexpr int STRIP = 4;
+        const unsigned per_strip = (unsigned)STRIP * (unsigned)q_tiles;
+        const int strip = (int)(id / per_strip);
+        const unsigned r = id % per_strip;
+        const int width = n_tiles - strip * STRIP < STRIP ? n_tiles - strip * STRIP : STRIP;
+        nt = strip * STRIP + (int)(r % (unsigned)width);
+        qt = (int)(r / (unsigned)width);
+    }
+    const int64_t n0 = (int64_t)nt * BT, q0 = (int64_t)qt * BT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wq = wave & 3;
+    const int rsub = lane >> 3, slot = lane & 7;
+    const int frow = lane & 15, fk = lane >> 4;
+
+    const int8_t *a_src[4], *b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + rsub;
+        int64_t gn = n0 + r, gq = q0 + r;
+        if (gn >= n_rows) gn = n_rows - 1;          // clamped duplicates are masked in the epilogue
+        if (gq >= nq) gq = nq - 1;
+        a_src[i] = bank + gn * stride + (slot ^ (r & 7)) * 16;
+        b_src[i] = query + gq * stride + (slot ^ (r & 7)) * 16;
+    }
+    auto stage = [&](int kt, char *buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl_glds16(a_src[i] + (int64_t)kt * TILE_K, buf + (wave * 4 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + (int64_t)kt * TILE_K, buf + BOPER + (wave * 4 + i) * 1024);
+    };
+
+    v4i acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+
+    const int nk = (int)(stride / TILE_K);
+    stage(0, smem);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        const char *cur = smem + (kt & 1) * 2 * BOPER;
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * 2 * BOPER);
+        const char *la = cur + (wn * 128) * TILE_K;
+        const char *lb = cur + BOPER + (wq * 64) * TILE_K;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + fk;
+            v4i a[8], b[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = i * 16 + frow;
+                a[i] = *reinterpret_cast<const v4i *>(la + r * TILE_K + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = j * 16 + frow;
+                b[j] = *reinterpret_cast<const v4i *>(lb + r * TILE_K + ((chunk ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    const int64_t nbase = n0 + wn * 128 + fk * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t q = q0 + wq * 64 + j * 16 + frow;
+        const unsigned qn = q < nq ? (unsigned)query_norm[q] : 0u;
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = nbase + i * 16 + r;
+                const unsigned bn = n < n_rows ? (unsigned)bank_norm[n] : 0u;
+                const unsigned long long s = bn + qn - 2u * (unsigned)acc[i][j][r];       // exact modulo 2^32, and S < 2^32
+                const unsigned long long key = (s << shift) | (unsigned long long)(index_base + n);
+                if (n < n_rows && key < best) best = key;
+            }
+        unsigned long long o = __shfl_xor(best, 16, 64);
+        best = o < best ? o : best;
+        o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -185,6 +293,20 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
         attr_set = true;
     }
     gl_prof_scope prof_(ctx, GL_PROF_L2_KNN);
+    // the large tile needs enough tiles to fill 256 CUs; GL_L2_TILE=128|256 forces one (tuning / tests)
+    static const int force_tile = getenv("GL_L2_TILE") ? atoi(getenv("GL_L2_TILE")) : 0;
+    const int64_t q256 = gl_ceil_div(nq, BT), n256 = gl_ceil_div(n_rows, BT);
+    if (d <= 66051 && force_tile != 128 && (force_tile == 256 || q256 * n256 >= 1024)) {
+        static bool attr256 = false;
+        if (!attr256) {
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BOPER));
+            attr256 = true;
+        }
+        hipLaunchKernelGGL(l2_knn_i8_256_kernel, dim3((unsigned)(q256 * n256)), dim3(512), 4 * BOPER, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows, index_base,
+                           query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q256, (int)n256, shift);
+        GL_LAUNCH_CHECK();
+        return GL_OK;
+    }
     auto kern = d > 66051 ? l2_knn_i8_kernel<true> : l2_knn_i8_kernel<false>;      // 65025 * 66051 < 2^32
     hipLaunchKernelGGL(kern, dim3((unsigned)(q_tiles * n_tiles)), dim3(THREADS), lds, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows,
                        index_base, query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
