@@ -28,6 +28,7 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 
 // WC x WP waves (channel direction x position direction), each owning 64 channels x 64 positions.
 //   <2,2>: 128 channels x 128 positions, 4 waves, 64 KiB LDS (2 workgroups per CU)
+//   <1,4>: 64 channels x 256 positions, 4 waves, 80 KiB LDS (2 workgroups per CU): layers with <= 64 output columns
 //   <2,4>: 128 channels x 256 positions, 8 waves, 96 KiB LDS (1 workgroup per CU): 25 % less staging per MFMA
 //   STAGES = 2: double buffer, __syncthreads() per slice (drains every load: prefetch distance one slice)
 //   STAGES = 3: ring of three slices, raw s_barrier + counted s_waitcnt vmcnt(N): the loads of slice k+2 are issued while
@@ -265,7 +266,7 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
     constexpr int HTC = 64 * WC, HTP = 64 * WP;
     const int64_t m_tiles = gl_ceil_div(p.positions, HTP);
-    const int n_tiles = p.cols_pad / HTC;
+    const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
     static bool attr_set = false;
     constexpr int lds = STAGES * (HTC + HTP) * HBK_BYTES;
@@ -304,6 +305,8 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     if (variant == 1 && p.positions >= 65536) return launch_h3<2, 4, 2>(ctx, p, phases);   // 128 ch x 256 positions, 8 waves, double buffer
     if (variant == 2 && p.positions >= 65536) return launch_h3<2, 4, 3>(ctx, p, phases);   // same tile, three-slice ring (144 KiB LDS)
     if (variant == 3) return launch_h3<2, 2, 3>(ctx, p, phases);                          // 128 x 128, three-slice ring (96 KiB, 1 WG/CU)
+    // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
+    if (p.cols <= 64 && variant != 4) return launch_h3<1, 4, 2>(ctx, p, phases);
     return launch_h3<2, 2, 2>(ctx, p, phases);
 }
 
