@@ -174,6 +174,13 @@ def unpack_keys(ctx, keys, nq, d, kind="u8"):
     return dist.numpy()[:nq], idx.numpy()[:nq]
 
 
+def _feature_row_bytes(ctx, model, images):
+    h, w = int(images.shape[2]), int(images.shape[3])
+    if model.search_rows == "fp16":
+        return 2 * int(ctx.lib.gl_lpips_search_dim(h, w))
+    return 4 * int(ctx.lib.gl_lpips_feature_dim(h, w))
+
+
 def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes):
     """bank rows [0, n_rows) pass through HBM in chunks of at most `chunk_bytes` of prepared rows (int8 rows for 'l2', feature
     rows for 'l2-lpips'); the packed keys accumulate the minimum across chunks (atomicMin), so the result is the one the
@@ -196,6 +203,15 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
 
     if distance == "l2-lpips":
         from . import lpips as _lp
+        if getattr(queries, "kind", None) != "feat" and len(queries):
+            # query rows that would not fit the budget either (256 x 256 images: 17 MB per search row) go in slices, each against
+            # the whole bank stream -- the bank's features are then recomputed once per slice
+            per_q = _feature_row_bytes(ctx, model, queries)
+            q_step = max(1, int(chunk_bytes // per_q))
+            if len(queries) > q_step:
+                parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes)
+                         for a in range(0, len(queries), q_step)]
+                return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=model.search_role("query"))
         b_role = "bank" if getattr(fq, "role", None) else None
         step = max(1, int(chunk_bytes // (fq.K * (2 if fq.role else 4))))
@@ -270,11 +286,13 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
         else:
             per_img = int(np.prod(tuple(bank.shape[1:]), dtype=np.int64)) if len(bank) else 0
             if distance == "l2-lpips" and len(bank):
-                per_img = 2 * int(ctx.lib.gl_lpips_search_dim(int(bank.shape[2]), int(bank.shape[3]))) if model.search_rows == "fp16" \
-                    else 4 * int(ctx.lib.gl_lpips_feature_dim(int(bank.shape[2]), int(bank.shape[3])))
+                per_img = _feature_row_bytes(ctx, model, bank)
+                if getattr(queries, "kind", None) != "feat" and len(queries) * per_img > chunk_bytes:
+                    need = chunk_bytes + 1           # the query rows alone exceed the budget: streamed form, queries in slices
+                else:
+                    need = per_img * n_rows
             else:
-                per_img *= 2             # u8 codes + int8 rows
-            need = per_img * n_rows
+                need = 2 * per_img * n_rows          # u8 codes + int8 rows
         if need > chunk_bytes:
             return _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes)
     if not prepared and n_rows > 0:

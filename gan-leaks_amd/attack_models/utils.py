@@ -41,14 +41,7 @@ def get_filepaths_from_dir(data_dir, ext):
     return sorted(path_list)
 
 
-def read_image_u8(filepath, resolution=64):
-    """the 8-bit codes read_image decodes (attack_models/utils.py:71-80): PIL open, and a PIL resize
-    (default filter) to resolution x resolution when the shape differs.  HWC uint8."""
-    import PIL.Image
-    img = np.asarray(PIL.Image.open(filepath))
-    if img.shape != (resolution, resolution, 3):
-        img = np.asarray(PIL.Image.fromarray(img).resize((resolution, resolution)))
-    return img
+from .._png_worker import read_image_u8  # noqa: E402,F401  (one definition, shared with the worker processes)
 
 
 def read_image(filepath, resolution=64, cx=89, cy=121):
@@ -56,12 +49,47 @@ def read_image(filepath, resolution=64, cx=89, cy=121):
     return 2.0 * (read_image_u8(filepath, resolution) / 255.0) - 1.0
 
 
-def read_images_u8_nchw(paths, resolution=64):
-    """all files -> uint8 [N,3,res,res] (the NCHW order fbb.main permutes to, fbb.py:135)."""
-    out = np.empty((len(paths), 3, resolution, resolution), np.uint8)
-    for i, f in enumerate(paths):
-        out[i] = read_image_u8(f, resolution).transpose(2, 0, 1)
-    return out
+def _io_workers(workers, items):
+    """worker processes for `items` files: $GANLEAKS_IO_PROCS or up to 16 (the CPU share of one GPU), one per 2048 files"""
+    if workers is None:
+        workers = int(os.environ.get("GANLEAKS_IO_PROCS", "0")) or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        workers = min(workers, items // 2048)
+    return max(1, int(workers))
+
+
+def run_png_workers(commands):
+    """start one `python _png_worker.py ...` per command, wait for all, raise if any failed"""
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_png_worker.py")
+    procs = [subprocess.Popen([sys.executable, script] + [str(a) for a in c], stderr=subprocess.PIPE) for c in commands]
+    errs = [(p.wait(), p.stderr.read().decode(errors="replace")) for p in procs]
+    bad = [e for rc, e in errs if rc != 0]
+    if bad:
+        raise RuntimeError("PNG worker failed: " + bad[0][-2000:])
+
+
+def read_images_u8_nchw(paths, resolution=64, workers=None):
+    """all files -> uint8 [N,3,res,res] (the NCHW order fbb.main permutes to, fbb.py:135).  The reference decodes the files one by
+    one (fbb.py:133-135: ~20 s per 100k 64x64 PNGs); large lists are split over worker PROCESSES (_png_worker.py) that fill slices
+    of one shared file.  Output order = input order; the bytes do not depend on the worker count."""
+    n = len(paths)
+    workers = _io_workers(workers, n)
+    if workers == 1 or any("\n" in p for p in paths):
+        out = np.empty((n, 3, resolution, resolution), np.uint8)
+        for i, f in enumerate(paths):
+            out[i] = read_image_u8(f, resolution).transpose(2, 0, 1)
+        return out
+    import tempfile
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(dir=shm) as tmp:
+        list_file, out_file = os.path.join(tmp, "paths.txt"), os.path.join(tmp, "bank.u8")
+        with open(list_file, "w") as f:
+            f.write("\n".join(paths))
+        np.memmap(out_file, np.uint8, "w+", shape=(n, 3, resolution, resolution)).flush()
+        step = -(-n // workers)
+        run_png_workers([("decode", list_file, lo, min(lo + step, n), resolution, out_file) for lo in range(0, n, step)])
+        return np.array(np.memmap(out_file, np.uint8, "r", shape=(n, 3, resolution, resolution)))
 
 
 class Loss:

@@ -78,3 +78,7 @@ def test_l2_lpips_streamed_equals_resident(gl, synth, golden_dir):
         row_bytes = (2 * int(gl.Context.get().lib.gl_lpips_search_dim(32, 32))) if rows == "fp16" else 4 * int(gl.Context.get().lib.gl_lpips_feature_dim(32, 32))
         d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=model, chunk_bytes=23 * row_bytes)
         assert np.array_equal(i, i0) and np.array_equal(d, d0) and i.max() < 64
+        # a budget smaller than the query rows: the queries go in slices of 5, each against the whole bank stream
+        d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=model, chunk_bytes=5 * row_bytes)
+        assert np.array_equal(i, i0) and np.array_equal(d, d0)
+    model.search_rows = "fp16"

@@ -27,6 +27,22 @@ def test_sorted_paths_and_read_image_match_reference(gl, golden_dir):
     assert np.array_equal(arr, g["images"])                                    # incl. the resized 24x24 file
     u8 = utils.read_images_u8_nchw(paths, 16)
     assert np.array_equal(2.0 * (u8.transpose(0, 2, 3, 1) / 255.0) - 1.0, g["images"])
+    # the worker-process form (used for banks of thousands of files) returns the same bytes in the same order
+    assert np.array_equal(utils.read_images_u8_nchw(paths, 16, workers=3), u8)
+
+
+def test_png_bank_round_trip_with_worker_processes(gl, tmp_path):
+    """save_png_bank -> load_png_bank: file names of the generate branch, string-sorted load order, identical bytes for any worker count"""
+    from ganleaks_amd import bank_io
+    imgs = np.random.default_rng(5).integers(0, 256, (23, 3, 16, 16), dtype=np.uint8)
+    for workers, sub in ((1, "a"), (4, "b")):
+        d = bank_io.save_png_bank(imgs, str(tmp_path / sub), workers=workers)
+        assert sorted(os.listdir(d)) == sorted("image_%d.png" % i for i in range(23))
+        bank, paths = bank_io.load_png_bank(d, 16, workers=workers)
+        assert np.array_equal(bank, imgs[bank_io.generation_order(paths)])
+    with pytest.raises(RuntimeError):
+        from ganleaks_amd.attack_models import utils
+        utils.read_images_u8_nchw([str(tmp_path / "missing.png")] * 4, 16, workers=2)
 
 
 @pytest.mark.parametrize("name", ["roc_sep", "roc_ties", "roc_small", "roc_knn_c1"])
