@@ -64,6 +64,9 @@ SIGNATURES = {
     "gl_keys_init": (_i, [_p, _p, _i64]),
     "gl_l2_knn_i8": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gl_keys_unpack": (_i, [_p, _p, _i64, _i64, _p, _p]),
+    "gl_encode_integers_f32": (_i, [_p, _p, _i64, _p, _p]),
+    "gl_decode_u8_integers": (_i, [_p, _p, _i64, _p]),
+    "gl_keys_unpack_integers": (_i, [_p, _p, _i64, _i64, _p, _p]),
     "gl_l2_rows_u8": (_i, [_p, _p, _i64, _p, _i64, _i64, _p]),
     "gl_l2_knn_f32": (_i, [_p, _p, _i64, _i64, _p, _i64, _i64, _p]),
     "gl_keys_unpack_f32": (_i, [_p, _p, _i64, _p, _p]),

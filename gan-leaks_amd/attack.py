@@ -4,10 +4,11 @@
 (attack_models/fbb.py:73-88): it must equal
     [custom_knn(bank, q, Loss(distance), args) for q in queries].
 
-Two arithmetic paths:
+Arithmetic paths:
   * images on the 8-bit lattice 2*(u/255.)-1 -- everything attack_models/utils.py:60-84 (read_image)
-    can produce -- are searched in exact integer arithmetic on the int8 matrix cores;
-  * any other fp32 images take the fixed-order fp32 path (csrc/gl_l2f32.hip).
+    can produce -- are searched in exact integer arithmetic on the int8 matrix cores (Bank kind 'u8');
+  * rows of small non-negative integers (binary / count tables, e.g. medGAN's thresholded samples) likewise (kind 'int');
+  * any other fp32 rows take the fixed-order fp32 path (csrc/gl_l2f32.hip, kind 'f32').
 """
 from __future__ import annotations
 
@@ -49,12 +50,14 @@ def _to_device_rows(ctx, images):
     return arr.view((count, d))
 
 
-def encode_if_lattice(ctx, rows_f32):
-    """float32 rows -> (u8 rows, off_lattice_count).  The u8 rows are only meaningful when the count is 0."""
+def encode_if_lattice(ctx, rows_f32, integers=False):
+    """float32 rows -> (u8 rows, off_lattice_count).  The u8 rows are only meaningful when the count is 0.
+    integers=False: the image lattice 2*(u/255.)-1; True: x == float(u), u in 0..255."""
     count, d = rows_f32.shape
     out = ctx.empty((count, d), np.uint8)
     flag = ctx.zeros((1,), np.int32)
-    check(ctx.lib.gl_encode_lattice_f32(ctx.handle, _p(rows_f32.ptr), count * d, _p(out.ptr), _p(flag.ptr)))
+    fn = ctx.lib.gl_encode_integers_f32 if integers else ctx.lib.gl_encode_lattice_f32
+    check(fn(ctx.handle, _p(rows_f32.ptr), count * d, _p(out.ptr), _p(flag.ptr)))
     return out, int(flag.numpy()[0])
 
 
@@ -72,7 +75,8 @@ def prepare_images(ctx, images):
 class Bank:
     """a sample bank (or query set) resident in HBM, prepared for one of the two L2 kernels.
 
-    kind 'u8' : biased int8 rows + int32 row norms (exact path)
+    kind 'u8' : biased int8 rows + int32 row norms (exact path), bytes are image codes: x = 2*(u/255.)-1
+    kind 'int': the same, bytes are the values themselves: x = float(u)  (float inputs only; uint8 input always means image codes)
     kind 'f32': the fp32 rows as given (fixed-order fp32 path)
     `index_base` is the global index of row 0 (non-zero for a shard of a larger bank)."""
 
@@ -86,23 +90,33 @@ class Bank:
         ctx = ctx or Context.get()
         rows = _to_device_rows(ctx, images)
         n, d = rows.shape
+        kind = "u8"
         if rows.dtype == np.float32:
-            u8, bad = (None, 1) if force_kind == "f32" else encode_if_lattice(ctx, rows)
+            u8, bad = None, 1
+            for cand in (("u8", "int") if force_kind is None else (force_kind,)):
+                if cand == "f32":
+                    break
+                u8, bad = encode_if_lattice(ctx, rows, integers=(cand == "int"))
+                if bad == 0:
+                    kind = cand
+                    break
             if bad:
-                if force_kind == "u8":
-                    raise ValueError("%d pixel values are not on the 8-bit lattice" % bad)
+                if force_kind in ("u8", "int"):
+                    raise ValueError("%d values are not on the %s" % (bad, "8-bit lattice" if force_kind == "u8" else "integer lattice 0..255"))
                 return cls(ctx, "f32", n, d, index_base, rows_f32=rows)
             rows = u8
         elif force_kind == "f32":
             f = ctx.empty((n, d), np.float32)
             check(ctx.lib.gl_decode_u8(ctx.handle, _p(rows.ptr), n * d, _p(f.ptr)))
             return cls(ctx, "f32", n, d, index_base, rows_f32=f)
+        elif force_kind == "int":
+            raise ValueError("uint8 input is read as image codes; pass float rows for the integer lattice")
         stride = int(ctx.lib.gl_l2_row_stride(d))
         rows_i8 = ctx.empty((n, stride), np.int8)
         norms = ctx.empty((max(n, 1),), np.int32)
         check(ctx.lib.gl_l2_prepare(ctx.handle, _p(rows.ptr), n, d, _p(rows_i8.ptr), _p(norms.ptr)))
         ctx.sync()
-        return cls(ctx, "u8", n, d, index_base, rows_i8=rows_i8, norms=norms, u8=rows if keep_u8 else None)
+        return cls(ctx, kind, n, d, index_base, rows_i8=rows_i8, norms=norms, u8=rows if keep_u8 else None)
 
     def as_f32(self):
         """an fp32 view of a u8 bank (needed when the other side of the comparison is off-lattice)."""
@@ -110,6 +124,10 @@ class Bank:
             return self
         if self.u8 is None:
             raise ValueError("bank was prepared without keep_u8; cannot convert to fp32")
+        if self.kind == "int":
+            f = self.ctx.empty((self.n, self.d), np.float32)
+            check(self.ctx.lib.gl_decode_u8_integers(self.ctx.handle, _p(self.u8.ptr), self.n * self.d, _p(f.ptr)))
+            return Bank(self.ctx, "f32", self.n, self.d, self.index_base, rows_f32=f)
         return Bank.from_images(self.u8, self.ctx, self.index_base, force_kind="f32")
 
     def __len__(self):
@@ -155,7 +173,7 @@ def knn_keys(bank, queries, n_rows=None, keys=None):
     if keys is None:
         keys = ctx.empty((max(queries.n, 1),), np.uint64)
         check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), queries.n))
-    if bank.kind == "u8":
+    if bank.kind in ("u8", "int"):
         check(ctx.lib.gl_l2_knn_i8(ctx.handle, _p(bank.rows_i8.ptr), _p(bank.norms.ptr), n_rows, bank.index_base,
                                    _p(queries.rows_i8.ptr), _p(queries.norms.ptr), queries.n, bank.d, _p(keys.ptr)))
     else:
@@ -169,6 +187,8 @@ def unpack_keys(ctx, keys, nq, d, kind="u8"):
     idx = ctx.empty((max(nq, 1),), np.int64)
     if kind == "u8":
         check(ctx.lib.gl_keys_unpack(ctx.handle, _p(keys.ptr), nq, d, _p(dist.ptr), _p(idx.ptr)))
+    elif kind == "int":
+        check(ctx.lib.gl_keys_unpack_integers(ctx.handle, _p(keys.ptr), nq, d, _p(dist.ptr), _p(idx.ptr)))
     else:
         check(ctx.lib.gl_keys_unpack_f32(ctx.handle, _p(keys.ptr), nq, _p(dist.ptr), _p(idx.ptr)))
     return dist.numpy()[:nq], idx.numpy()[:nq]
@@ -225,9 +245,9 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
     # 'l2': every chunk must take the same arithmetic path.  Exact integers unless the queries or some chunk are off the 8-bit lattice;
     # then everything is redone on the fixed-order fp32 path (what the resident form does for such inputs).
     fq = queries if isinstance(queries, Bank) else Bank.from_images(queries, ctx, keep_u8=True)
-    for force in (("u8", "f32") if fq.kind == "u8" else ("f32",)):
+    for force in ((fq.kind, "f32") if fq.kind != "f32" else ("f32",)):
         q_side = fq if fq.kind == force else fq.as_f32()
-        step = max(1, int(chunk_bytes // ((2 if force == "u8" else 4) * fq.d)))
+        step = max(1, int(chunk_bytes // ((4 if force == "f32" else 2) * fq.d)))
         keys, ok = None, True
         for lo in range(0, n_rows, step):
             hi = min(lo + step, n_rows)

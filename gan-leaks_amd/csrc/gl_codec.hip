@@ -16,11 +16,13 @@ inline int stream_grid(int64_t work_items)
 
 // x == fl32(2*(u/255.)-1)?  table built once per block from the same float64 expression the
 // reference evaluates (attack_models/utils.py:82), so the comparison is exact.
+// INT = true: the integer lattice x == (float)u, u in 0..255 (binary / count tables such as medGAN's thresholded rows)
+template <bool INT>
 __global__ void __launch_bounds__(kThreads) encode_lattice_kernel(const float *__restrict__ x, int64_t count,
                                                                   uint8_t *__restrict__ out, int32_t *__restrict__ off)
 {
     __shared__ float lut[256];
-    if (threadIdx.x < 256) lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
+    if (threadIdx.x < 256) lut[threadIdx.x] = INT ? (float)threadIdx.x : (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
     __syncthreads();
     int bad = 0;
     const int64_t n4 = count >> 2;
@@ -31,7 +33,7 @@ __global__ void __launch_bounds__(kThreads) encode_lattice_kernel(const float *_
         uint32_t packed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float t = rintf((f[k] + 1.0f) * 127.5f);
+            float t = INT ? rintf(f[k]) : rintf((f[k] + 1.0f) * 127.5f);
             t = fminf(fmaxf(t, 0.0f), 255.0f);
             const int u = (int)t;
             bad += (lut[u] != f[k]);   // NaN compares unequal -> counted
@@ -42,7 +44,7 @@ __global__ void __launch_bounds__(kThreads) encode_lattice_kernel(const float *_
     // tail (count % 4) handled by block 0
     if (blockIdx.x == 0) {
         for (int64_t i = (n4 << 2) + threadIdx.x; i < count; i += blockDim.x) {
-            float t = rintf((x[i] + 1.0f) * 127.5f);
+            float t = INT ? rintf(x[i]) : rintf((x[i] + 1.0f) * 127.5f);
             t = fminf(fmaxf(t, 0.0f), 255.0f);
             const int u = (int)t;
             bad += (lut[u] != x[i]);
@@ -52,10 +54,11 @@ __global__ void __launch_bounds__(kThreads) encode_lattice_kernel(const float *_
     if (bad) atomicAdd(off, bad);
 }
 
+template <bool INT>
 __global__ void __launch_bounds__(kThreads) decode_u8_kernel(const uint8_t *__restrict__ u8, int64_t count, float *__restrict__ x)
 {
     __shared__ float lut[256];
-    if (threadIdx.x < 256) lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
+    if (threadIdx.x < 256) lut[threadIdx.x] = INT ? (float)threadIdx.x : (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
     __syncthreads();
     const int64_t n4 = count >> 2;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -172,13 +175,16 @@ __global__ void __launch_bounds__(kThreads) l2_rows_u8_kernel(const uint8_t *__r
     }
 }
 
+// INT: dist = fl32(S / d) -- the double quotient rounded once more to fp32 is the correctly rounded fp32 quotient (53 >= 2*24+2),
+// i.e. what an fp32 `sum / d` gives while the sum is exact
+template <bool INT>
 __global__ void __launch_bounds__(kThreads) keys_unpack_kernel(const uint64_t *__restrict__ keys, int64_t nq, double scale, int shift,
                                                                float *__restrict__ dist, int64_t *__restrict__ idx)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const uint64_t k = keys[i];
-    dist[i] = (float)((double)(k >> shift) * scale);   // fl32(S * 4/(255^2 D)), same expression as the oracle
+    dist[i] = INT ? (float)((double)(k >> shift) / scale) : (float)((double)(k >> shift) * scale);   // fl32(S * 4/(255^2 D)), same expression as the oracle
     idx[i] = (int64_t)(k & ((1ull << shift) - 1ull));
 }
 
@@ -186,29 +192,47 @@ __global__ void __launch_bounds__(kThreads) keys_unpack_kernel(const uint64_t *_
 
 extern "C" {
 
-int gl_encode_lattice_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev)
+static int encode_impl(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev, bool integers)
 {
-    GL_REQUIRE(ctx && count >= 0, "gl_encode_lattice_f32: bad ctx/count");
+    GL_REQUIRE(ctx && count >= 0, "gl_encode_*_f32: bad ctx/count");
     if (count == 0) return GL_OK;
-    GL_REQUIRE(x_dev && u8_dev && off_lattice_dev, "gl_encode_lattice_f32: NULL device pointer");
+    GL_REQUIRE(x_dev && u8_dev && off_lattice_dev, "gl_encode_*_f32: NULL device pointer");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(u8_dev) & 3) == 0,
-               "gl_encode_lattice_f32: x_dev must be 16-byte and u8_dev 4-byte aligned");
-    hipLaunchKernelGGL(encode_lattice_kernel, dim3(stream_grid(count / 4)), dim3(kThreads), 0, ctx->stream, x_dev, count, u8_dev, off_lattice_dev);
+               "gl_encode_*_f32: x_dev must be 16-byte and u8_dev 4-byte aligned");
+    if (integers)
+        hipLaunchKernelGGL(encode_lattice_kernel<true>, dim3(stream_grid(count / 4)), dim3(kThreads), 0, ctx->stream, x_dev, count, u8_dev, off_lattice_dev);
+    else
+        hipLaunchKernelGGL(encode_lattice_kernel<false>, dim3(stream_grid(count / 4)), dim3(kThreads), 0, ctx->stream, x_dev, count, u8_dev, off_lattice_dev);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
 
-int gl_decode_u8(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev)
+static int decode_impl(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev, bool integers)
 {
-    GL_REQUIRE(ctx && count >= 0, "gl_decode_u8: bad ctx/count");
+    GL_REQUIRE(ctx && count >= 0, "gl_decode_u8*: bad ctx/count");
     if (count == 0) return GL_OK;
-    GL_REQUIRE(x_dev && u8_dev, "gl_decode_u8: NULL device pointer");
+    GL_REQUIRE(x_dev && u8_dev, "gl_decode_u8*: NULL device pointer");
     GL_REQUIRE((reinterpret_cast<uintptr_t>(x_dev) & 15) == 0 && (reinterpret_cast<uintptr_t>(u8_dev) & 3) == 0,
-               "gl_decode_u8: x_dev must be 16-byte and u8_dev 4-byte aligned");
-    hipLaunchKernelGGL(decode_u8_kernel, dim3(stream_grid(count / 4)), dim3(kThreads), 0, ctx->stream, u8_dev, count, x_dev);
+               "gl_decode_u8*: x_dev must be 16-byte and u8_dev 4-byte aligned");
+    if (integers) hipLaunchKernelGGL(decode_u8_kernel<true>, dim3(stream_grid(count / 4)), dim3(kThreads), 0, ctx->stream, u8_dev, count, x_dev);
+    else hipLaunchKernelGGL(decode_u8_kernel<false>, dim3(stream_grid(count / 4)), dim3(kThreads), 0, ctx->stream, u8_dev, count, x_dev);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
+
+int gl_encode_lattice_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev)
+{
+    return encode_impl(ctx, x_dev, count, u8_dev, off_lattice_dev, false);
+}
+
+int gl_encode_integers_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev)
+{
+    return encode_impl(ctx, x_dev, count, u8_dev, off_lattice_dev, true);
+}
+
+int gl_decode_u8(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev) { return decode_impl(ctx, u8_dev, count, x_dev, false); }
+
+int gl_decode_u8_integers(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev) { return decode_impl(ctx, u8_dev, count, x_dev, true); }
 
 int gl_quantize_f32(gl_ctx *ctx, const float *x_dev, int64_t count, int mode, uint8_t *u8_dev)
 {
@@ -272,7 +296,18 @@ int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d,
     if (nq == 0) return GL_OK;
     GL_REQUIRE(keys_dev && dist_dev && idx_dev, "gl_keys_unpack: NULL device pointer");
     const double scale = 4.0 / (65025.0 * (double)d);
-    hipLaunchKernelGGL(keys_unpack_kernel, dim3((int)gl_ceil_div(nq, kThreads)), dim3(kThreads), 0, ctx->stream, keys_dev, nq, scale, gl_l2_key_shift(d), dist_dev, idx_dev);
+    hipLaunchKernelGGL(keys_unpack_kernel<false>, dim3((int)gl_ceil_div(nq, kThreads)), dim3(kThreads), 0, ctx->stream, keys_dev, nq, scale, gl_l2_key_shift(d), dist_dev, idx_dev);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_keys_unpack_integers(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d, float *dist_dev, int64_t *idx_dev)
+{
+    GL_REQUIRE(ctx && nq >= 0 && d > 0, "gl_keys_unpack_integers: bad ctx/nq/d");
+    if (nq == 0) return GL_OK;
+    GL_REQUIRE(keys_dev && dist_dev && idx_dev, "gl_keys_unpack_integers: NULL device pointer");
+    hipLaunchKernelGGL(keys_unpack_kernel<true>, dim3((int)gl_ceil_div(nq, kThreads)), dim3(kThreads), 0, ctx->stream, keys_dev, nq, (double)d, gl_l2_key_shift(d), dist_dev,
+                       idx_dev);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -116,6 +116,12 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
                  const int8_t *query_i8_dev, const int32_t *query_norm_dev, int64_t nq, int64_t d, uint64_t *keys_dev);
 /* keys -> (distance fp32 = fl32(S * 4/(255^2 d)), index int64).  `min_distance.item(), indices[min_index].item()`, fbb.py:88 */
 int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d, float *dist_dev, int64_t *idx_dev);
+/* The same exact path for tables of small non-negative integers (x == (float)u, u in 0..255: binary / count rows such as medGAN's thresholded
+ * output, gan_models/medgan/train.py:306-312): encode to bytes, gl_l2_prepare + gl_l2_knn_i8 as for images, and
+ * dist = fl32(S / d) = what an fp32 mean((y-x)^2) gives while its sum is exact (S < 2^24).  off_lattice_dev counts values that are not such integers. */
+int gl_encode_integers_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev);
+int gl_decode_u8_integers(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev);
+int gl_keys_unpack_integers(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d, float *dist_dev, int64_t *idx_dev);
 
 /* out[i] = fl32(S(x_hat[i], x_gt[b_gt == 1 ? 0 : i]) * 4/(255^2 d)), i < b: the per-sample loss vector
  * Loss('l2').forward(x_hat, x_gt) returns (attack_models/utils.py:163,169,171-177; x_gt broadcasts

@@ -170,6 +170,36 @@ def test_large_images_exact(shape, gl, coracle):
         Bank.from_images(np.zeros((2, 262144), np.uint8), ctx)
 
 
+def test_integer_tables_take_the_exact_path(gl, coracle):
+    """binary / count rows given as floats (medGAN's thresholded samples, medgan/train.py:306-312) are searched on the int8 matrix
+    cores; the result equals the fixed-order fp32 path bit for bit (all sums are exact integers) and the C oracle's S / F"""
+    from ganleaks_amd.attack import Bank, knn_keys, unpack_keys
+    rng = np.random.default_rng(11)
+    F = 1071
+    for hi in (2, 12):                                                   # {0,1} and small counts
+        bank = rng.integers(0, hi, size=(300, F)).astype(np.float32)
+        q = rng.integers(0, hi, size=(37, F)).astype(np.float32)
+        q[3] = bank[170]
+        ctx = gl.Context.get()
+        assert Bank.from_images(bank, ctx).kind == "int"
+        d, i = gl.attack(q, bank, batch_size=64)
+        _, oi, ssd = coracle.knn_l2_u8(bank.astype(np.uint8), q.astype(np.uint8), 64)
+        assert np.array_equal(i, oi) and np.array_equal(d, (ssd.astype(np.float64) / F).astype(np.float32))
+        assert i[3] == 170 and d[3] == 0 and i.max() < 256
+        kf, qf, kind = knn_keys(Bank.from_images(bank[:256], ctx, force_kind="f32"), Bank.from_images(q, ctx, force_kind="f32"))
+        df, if_ = unpack_keys(ctx, kf, 37, F, kind)
+        assert kind == "f32" and np.array_equal(if_, i) and np.array_equal(df, d)
+        ds, is_ = gl.attack(q, bank, batch_size=64, chunk_bytes=50 * 2 * F)          # streamed, same path
+        assert np.array_equal(is_, i) and np.array_equal(ds, d)
+    # one non-integer query value: everything moves to the fp32 path, same answer up to fp32 rounding of that row
+    q2 = q.copy()
+    q2[0, 0] += 0.25
+    d2, i2 = gl.attack(q2, bank, batch_size=64)
+    assert np.array_equal(i2[1:], i[1:]) and np.array_equal(d2[1:], d[1:])
+    with pytest.raises(ValueError):
+        Bank.from_images(q2, gl.Context.get(), force_kind="int")
+
+
 def test_shard_invariance(gl, synth, coracle):
     """any split of the bank into index-based shards gives bit-identical (dist, idx)"""
     from ganleaks_amd.attack import Bank, knn_keys, unpack_keys
