@@ -118,6 +118,32 @@ def test_vs_fp64_oracle_ragged_and_shards(gl, synth, model, lin, oracle):
         feat_knn_keys(model.features(bank[:8]), model.features(q, role="query"))
 
 
+def test_larger_images(gl, synth, model, lin, oracle):
+    """128 x 128 against the fp64 oracle (10 images: a few seconds of CPU); 256 x 256 (a search row is 17 MB, PGGAN-256's size) only
+    for agreement between the two row formats and between the streamed and the resident form"""
+    import lpips_oracle
+    sd = synth.vgg16_state_dict(7)
+    linl = [lin["lin%d" % i] for i in range(5)]
+    case = synth.attack_case(131, 8, 1, 1, 128, sigma=20.0)
+    bank, q = case["bank"], np.concatenate([case["pos"], case["neg"]])
+    od, oi, _ = lpips_oracle.knn_l2_lpips(sd, linl, oracle.dequantize_u8(bank), oracle.dequantize_u8(q), 4)
+    d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=4, lpips=model)
+    assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
+    case = synth.attack_case(133, 12, 2, 1, 256, sigma=20.0)
+    bank, q = case["bank"], np.concatenate([case["pos"], case["neg"]])
+    res = {}
+    for rows in ("fp16", "split"):
+        model.search_rows = rows
+        try:
+            res[rows] = gl.attack(q, bank, distance="l2-lpips", batch_size=4, lpips=model)
+        finally:
+            model.search_rows = "fp16"
+    assert np.array_equal(res["fp16"][1], res["split"][1]) and np.abs(res["fp16"][0] - res["split"][0]).max() < 2e-6
+    row = 2 * int(gl.Context.get().lib.gl_lpips_search_dim(256, 256))
+    ds, is_ = gl.attack(q, bank, distance="l2-lpips", batch_size=4, lpips=model, chunk_bytes=2 * row)      # bank in 6 chunks, queries in 2 slices
+    assert np.array_equal(is_, res["fp16"][1]) and np.array_equal(ds, res["fp16"][0])
+
+
 def test_search_rows_multi_tile(gl, synth, model):
     """600 bank rows x 300 queries: several 256 x 256 tiles with ragged edges in both directions.  No CPU oracle at this size
     (VGG16 in fp64 takes minutes); the split-row search, itself pinned to the oracle above, is the reference."""
