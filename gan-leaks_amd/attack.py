@@ -118,6 +118,20 @@ class Bank:
         ctx.sync()
         return cls(ctx, kind, n, d, index_base, rows_i8=rows_i8, norms=norms, u8=rows if keep_u8 else None)
 
+    def split_rows(self):
+        """(V, norms, scales) of an 'f32' bank for the matrix-core search (gl_rows_knn_split); built once, kept"""
+        if self.kind != "f32":
+            raise ValueError("split_rows() is for fp32 banks")
+        if getattr(self, "_split", None) is None:
+            ctx = self.ctx
+            kp = int(ctx.lib.gl_rows_split_dim(self.d))
+            V = ctx.empty((max(self.n, 1), kp), np.float32)
+            norms = ctx.empty((max(self.n, 1),), np.float32)
+            scales = ctx.empty((max(self.n, 1),), np.float32)
+            check(ctx.lib.gl_rows_split_f32(ctx.handle, _p(self.rows_f32.ptr), self.n, self.d, _p(V.ptr), _p(norms.ptr), _p(scales.ptr)))
+            self._split = (V, norms, scales)
+        return self._split
+
     def as_f32(self):
         """an fp32 view of a u8 bank (needed when the other side of the comparison is off-lattice)."""
         if self.kind == "f32":
@@ -158,7 +172,17 @@ def _budget_bytes():
     return int(float(os.environ.get("GANLEAKS_CHUNK_GB", "64")) * (1 << 30))
 
 
-def knn_keys(bank, queries, n_rows=None, keys=None):
+def float_path(value=None):
+    """how off-lattice fp32 rows are searched: 'exact' (default; VALU, one fixed fp32 order shared bit for bit with the oracle) or
+    'mfma' (split-fp16 on the matrix cores, |y|^2 + |x|^2 - 2 y.x; distances agree to ~3e-6 * mean(x^2), 15-60x faster).  $GANLEAKS_FLOAT_PATH."""
+    import os
+    value = value or os.environ.get("GANLEAKS_FLOAT_PATH", "exact")
+    if value not in ("exact", "mfma"):
+        raise ValueError("float path must be 'exact' or 'mfma', got %r" % (value,))
+    return value
+
+
+def knn_keys(bank, queries, n_rows=None, keys=None, fpath=None):
     """launch the pairwise kernel: packed keys DeviceArray [Q] (uint64), min over bank rows [0, n_rows).
     u8 path: (S << 32) | global index; f32 path: (float_bits(dist) << 32) | global index.  Asynchronous."""
     ctx = bank.ctx
@@ -176,6 +200,10 @@ def knn_keys(bank, queries, n_rows=None, keys=None):
     if bank.kind in ("u8", "int"):
         check(ctx.lib.gl_l2_knn_i8(ctx.handle, _p(bank.rows_i8.ptr), _p(bank.norms.ptr), n_rows, bank.index_base,
                                    _p(queries.rows_i8.ptr), _p(queries.norms.ptr), queries.n, bank.d, _p(keys.ptr)))
+    elif float_path(fpath) == "mfma":
+        (bv, bn, bs), (qv, qn, qs) = bank.split_rows(), queries.split_rows()
+        check(ctx.lib.gl_rows_knn_split(ctx.handle, _p(bv.ptr), _p(bn.ptr), _p(bs.ptr), n_rows, bank.index_base, _p(qv.ptr), _p(qn.ptr), _p(qs.ptr),
+                                        queries.n, bank.d, _p(keys.ptr)))
     else:
         check(ctx.lib.gl_l2_knn_f32(ctx.handle, _p(bank.rows_f32.ptr), n_rows, bank.index_base, _p(queries.rows_f32.ptr), queries.n, bank.d,
                                     _p(keys.ptr)))
@@ -201,7 +229,7 @@ def _feature_row_bytes(ctx, model, images):
     return 4 * int(ctx.lib.gl_lpips_feature_dim(h, w))
 
 
-def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes):
+def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath=None):
     """bank rows [0, n_rows) pass through HBM in chunks of at most `chunk_bytes` of prepared rows (int8 rows for 'l2', feature
     rows for 'l2-lpips'); the packed keys accumulate the minimum across chunks (atomicMin), so the result is the one the
     resident form gives.  `bank` is a GeneratedBank or a host array / DeviceArray of images."""
@@ -229,7 +257,7 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
             per_q = _feature_row_bytes(ctx, model, queries)
             q_step = max(1, int(chunk_bytes // per_q))
             if len(queries) > q_step:
-                parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes)
+                parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath)
                          for a in range(0, len(queries), q_step)]
                 return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=model.search_role("query"))
@@ -256,14 +284,14 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
             except ValueError:           # an off-lattice chunk
                 ok = False
                 break
-            keys, _, _ = knn_keys(b, q_side, keys=keys)
+            keys, _, _ = knn_keys(b, q_side, keys=keys, fpath=fpath)
             ctx.sync()
         if ok:
             return finish(keys, fq.n, fq.d, force)
     raise AssertionError("unreachable")
 
 
-def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None, chunk_bytes=None):
+def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None, chunk_bytes=None, float_path=None):
     """nearest bank sample of every query.
 
     queries : [Q,C,H,W] images, u8 or float; numpy / torch / DeviceArray / Bank / FeatureBank
@@ -278,6 +306,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
     returns (dist float32 [Q], idx int64 [Q]); idx < (N // batch_size) * batch_size (fbb.py:77),
     smallest index on ties (fbb.py:86).
     reduce_fn: optional callable(keys DeviceArray) -> keys DeviceArray, the cross-GPU min (shard.py).
+    float_path: 'exact' | 'mfma' for rows that are on neither lattice (see attack.float_path; default $GANLEAKS_FLOAT_PATH or 'exact').
     """
     if distance not in ("l2", "l2-lpips"):
         raise ValueError("distance must be 'l2' or 'l2-lpips', got %r" % (distance,))
@@ -314,7 +343,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
             else:
                 need = 2 * per_img * n_rows          # u8 codes + int8 rows
         if need > chunk_bytes:
-            return _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes)
+            return _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, float_path)
     if not prepared and n_rows > 0:
         if isinstance(bank, DeviceArray):
             bank = bank.view((n_rows,) + tuple(bank.shape[1:]))
@@ -332,7 +361,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
 
     if not prepared:
         bank = Bank.from_images(bank, ctx, keep_u8=True)
-    keys, q, kind = knn_keys(bank, queries, n_rows)
+    keys, q, kind = knn_keys(bank, queries, n_rows, fpath=float_path)
     if reduce_fn is not None:
         keys = reduce_fn(keys)
     return unpack_keys(ctx, keys, q.n, bank.d, kind)

@@ -437,6 +437,53 @@ void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, c
     }
 }
 
+// generic fp32 rows for the split-fp16 search (gl_rows_knn_split): one workgroup per row.
+//   e = the largest power of two with max|x| * 2^e <= 2^15   (per ROW, so rows of very different magnitude keep ~22 bits each)
+//   V[row] = hi + lo halves of x * 2^e in the split layout, zero padded to Kp;  norms[row] = sum x^2 / d;  scales[row] = 2^-e
+__global__ void __launch_bounds__(256) rows_split_kernel(const float *__restrict__ x, int64_t n, int64_t d, int64_t Kp, char *__restrict__ V,
+                                                         float *__restrict__ norms, float *__restrict__ scales)
+{
+    __shared__ double red[256];
+    __shared__ float redm[256];
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const float *row = x + r * d;
+        float m = 0.0f, s0 = 0.0f, s1 = 0.0f;
+        for (int64_t k = threadIdx.x; k < d; k += 512) {
+            const float a = row[k], b = (k + 256 < d) ? row[k + 256] : 0.0f;
+            m = fmaxf(m, fmaxf(fabsf(a), fabsf(b)));
+            s0 = fmaf(a, a, s0);
+            s1 = fmaf(b, b, s1);
+        }
+        red[threadIdx.x] = (double)s0 + (double)s1;
+        redm[threadIdx.x] = m;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) { red[threadIdx.x] += red[threadIdx.x + o]; redm[threadIdx.x] = fmaxf(redm[threadIdx.x], redm[threadIdx.x + o]); }
+            __syncthreads();
+        }
+        const float mx = redm[0];
+        int e = 0;
+        if (mx > 0.0f && mx < __builtin_inff()) {
+            int ex;
+            (void)frexpf(mx, &ex);                 // mx = f * 2^ex, f in [0.5, 1)
+            e = 15 - ex;                           // mx * 2^e in [2^14, 2^15)
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float up = ldexpf(1.0f, e);
+        if (threadIdx.x == 0) { norms[r] = (float)(red[0] / (double)d); scales[r] = ldexpf(1.0f, -e); }
+        char *dst = V + r * Kp * 4;
+        for (int64_t k = threadIdx.x; k < Kp; k += 256) {
+            const float v = k < d ? row[k] * up : 0.0f;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            char *p = dst + split_off(k);
+            *reinterpret_cast<_Float16 *>(p) = hi;
+            *reinterpret_cast<_Float16 *>(p + 64) = lo;
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // pairwise |V_q - V_n|^2 + argmin on the fp16 matrix cores, split operands (see gl_conv_h3.hip):
 // C[n][q] = sum_k (hi_n hi_q + hi_n lo_q + lo_n hi_q) = 2^28 * V_n . V_q   (v_mfma_f32_16x16x32_f16, fp32 accumulate)
@@ -451,8 +498,10 @@ constexpr int FT = 128, FROW = 128, FOPER = FT * FROW;
 __global__ void __launch_bounds__(256, 2)
 feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                 const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K,
-                unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+                unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, float inv_s2, const float *__restrict__ bank_scale,
+                const float *__restrict__ query_scale)
 {
+    // inv_s2: 1 / (scale of the stored halves)^2; bank_scale / query_scale (optional): per-row factors 2^-e of rows stored as x * 2^e
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
     int qt, nt;
@@ -516,27 +565,28 @@ feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_no
     }
 
     // epilogue: C tile 16x16: column (query) = lane & 15, row (bank) = 4 * (lane >> 4) + reg
-    const float inv_s2 = 1.0f / (kVScale * kVScale);
     const int64_t nbase = n0 + wn * 64 + fk * 4;
-    float bn[4][4];
+    float bn[4][4], bs[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t n = nbase + i * 16 + r;
             bn[i][r] = n < n_rows ? bank_norm[n] : 0.0f;
+            bs[i][r] = (bank_scale && n < n_rows) ? bank_scale[n] : 1.0f;
         }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int64_t q = q0 + wq * 64 + j * 16 + frow;
         const float qn = q < nq ? query_norm[q] : 0.0f;
+        const float qs = -2.0f * inv_s2 * ((query_scale && q < nq) ? query_scale[q] : 1.0f);
         unsigned long long best = ~0ull;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int64_t n = nbase + i * 16 + r;
-                const float d = fmaxf(fmaf(-2.0f * inv_s2, acc[i][j][r], __fadd_rn(qn, bn[i][r])), 0.0f);
+                const float d = fmaxf(fmaf(qs * bs[i][r], acc[i][j][r], __fadd_rn(qn, bn[i][r])), 0.0f);
                 const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
                 if (n < n_rows && key < best) best = key;
             }
@@ -1020,7 +1070,46 @@ int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev
     }
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
     hipLaunchKernelGGL(feat_knn_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, reinterpret_cast<const char *>(bank_V_dev), bank_norm_dev, n_rows,
-                       index_base, reinterpret_cast<const char *>(query_V_dev), query_norm_dev, nq, K, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles);
+                       index_base, reinterpret_cast<const char *>(query_V_dev), query_norm_dev, nq, K, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles,
+                       1.0f / (kVScale * kVScale), (const float *)nullptr, (const float *)nullptr);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int64_t gl_rows_split_dim(int64_t d) { return d <= 0 ? 0 : gl_ceil_div(d, 32) * 32; }
+
+int gl_rows_split_f32(gl_ctx *ctx, const float *rows_f32_dev, int64_t n, int64_t d, void *V_dev, float *norms_dev, float *scales_dev)
+{
+    GL_REQUIRE(ctx && n >= 0 && d > 0, "gl_rows_split_f32: bad sizes");
+    if (n == 0) return GL_OK;
+    GL_REQUIRE(rows_f32_dev && V_dev && norms_dev && scales_dev, "gl_rows_split_f32: NULL device pointer");
+    GL_REQUIRE((reinterpret_cast<uintptr_t>(V_dev) & 15) == 0, "gl_rows_split_f32: V must be 16-byte aligned");
+    hipLaunchKernelGGL(rows_split_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(256), 0, ctx->stream, rows_f32_dev, n, d, gl_rows_split_dim(d),
+                       reinterpret_cast<char *>(V_dev), norms_dev, scales_dev);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
+}
+
+int gl_rows_knn_split(gl_ctx *ctx, const void *bank_V_dev, const float *bank_norm_dev, const float *bank_scale_dev, int64_t n_rows, int64_t index_base,
+                      const void *query_V_dev, const float *query_norm_dev, const float *query_scale_dev, int64_t nq, int64_t d, uint64_t *keys_dev)
+{
+    GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && d > 0, "gl_rows_knn_split: bad sizes");
+    GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_rows_knn_split: global index does not fit 32 bits");
+    if (n_rows == 0 || nq == 0) return GL_OK;
+    GL_REQUIRE(bank_V_dev && bank_norm_dev && bank_scale_dev && query_V_dev && query_norm_dev && query_scale_dev && keys_dev, "gl_rows_knn_split: NULL device pointer");
+    GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V_dev) | reinterpret_cast<uintptr_t>(query_V_dev)) & 15) == 0, "gl_rows_knn_split: rows must be 16-byte aligned");
+    const int64_t q_tiles = gl_ceil_div(nq, FT), n_tiles = gl_ceil_div(n_rows, FT);
+    GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_rows_knn_split: grid too large");
+    static bool attr_set = false;
+    const int lds = 4 * FOPER;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
+    hipLaunchKernelGGL(feat_knn_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, reinterpret_cast<const char *>(bank_V_dev), bank_norm_dev, n_rows,
+                       index_base, reinterpret_cast<const char *>(query_V_dev), query_norm_dev, nq, gl_rows_split_dim(d), reinterpret_cast<unsigned long long *>(keys_dev),
+                       (int)q_tiles, (int)n_tiles, (float)(1.0 / (double)d), bank_scale_dev, query_scale_dev);
     GL_LAUNCH_CHECK();
     return GL_OK;
 }

@@ -245,6 +245,14 @@ int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t 
 /* gl_feat_knn on search rows: same keys, one fp16 MFMA per product, 256 x 256 tiles.  K1 = gl_lpips_search_dim. */
 int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
                    const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev);
+/* mean((y-x)^2) + argmin for ARBITRARY fp32 rows on the matrix cores (an alternative to the bit-reproducible VALU path gl_l2_knn_f32; ~15-60x
+ * faster; distances agree to ~3e-6 * mean(x^2), i.e. ~1e-6 absolute for rows in [-1,1]): rows are stored as hi + lo halves of x * 2^e with a per-row power of two,
+ * dist = |y|^2/d + |x|^2/d - 2 y.x/d with three fp16 MFMAs per product and fp32 accumulation.  V_dev: [n][gl_rows_split_dim(d)] 4-byte slots,
+ * norms_dev [n] = |x|^2 / d, scales_dev [n] = 2^-e.  Keys as gl_l2_knn_f32 (unpack with gl_keys_unpack_f32). */
+int64_t gl_rows_split_dim(int64_t d);
+int gl_rows_split_f32(gl_ctx *ctx, const float *rows_f32_dev, int64_t n, int64_t d, void *V_dev, float *norms_dev, float *scales_dev);
+int gl_rows_knn_split(gl_ctx *ctx, const void *bank_V_dev, const float *bank_norm_dev, const float *bank_scale_dev, int64_t n_rows, int64_t index_base,
+                      const void *query_V_dev, const float *query_norm_dev, const float *query_scale_dev, int64_t nq, int64_t d, uint64_t *keys_dev);
 /* Loss('l2-lpips').forward: per row, out_lpips = LPIPS and out_l2 = mean((y-x)^2) between V_hat[i] and V_gt[b_gt == 1 ? 0 : i];
  * K_lp = K - 3 H W is the length of the LPIPS part of V */
 int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,

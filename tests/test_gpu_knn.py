@@ -257,6 +257,32 @@ def test_float_path_vs_oracle(shape, gl, coracle):
     assert np.array_equal(i, oi) and np.array_equal(d, od)
 
 
+@pytest.mark.parametrize("shape", [(3, 32, 32), (1071,), (37,)])
+def test_float_rows_on_the_matrix_cores(shape, gl, coracle):
+    """float_path='mfma': |y|^2 + |x|^2 - 2 y.x with split-fp16 operands and a per-row power-of-two scale.  Not bit-reproducible
+    against the oracle's fixed fp32 order, so: same indices where the top-2 gap exceeds the error, distances within
+    4e-6 * mean(x^2) (fp32 accumulation of the dot product, exposed by the cancellation) + 1e-6 relative."""
+    rng = np.random.default_rng(shape[-1])
+    bank = rng.uniform(-1, 1, size=(700,) + shape).astype(np.float32)
+    q = rng.uniform(-1, 1, size=(150,) + shape).astype(np.float32)
+    # rows of very different magnitude (tabular counts next to fractions), an exact copy, an all-zero row
+    bank[100:200] *= 300.0
+    q[10:20] *= 300.0
+    bank[5] = 0.0
+    q[3] = bank[17]
+    q[4] = bank[150]
+    de, ie = gl.attack(q, bank, batch_size=64, float_path="exact")
+    dm, im = gl.attack(q, bank, batch_size=64, float_path="mfma")
+    od, oi = coracle.knn_l2_f32(bank, q, 64)
+    assert np.array_equal(ie, oi) and np.array_equal(de, od)
+    assert np.array_equal(im, ie)
+    scale = np.maximum(1.0, (q.reshape(len(q), -1) ** 2).mean(axis=1))          # error scales with |x|^2 / d
+    assert (np.abs(dm - de) <= 4e-6 * scale + 1e-6 * de).all(), np.abs(dm - de).max()
+    assert dm[3] <= 2e-6 and dm[4] <= 2e-6 * 300 ** 2 and im[3] == 17 and im[4] == 150
+    ds, is_ = gl.attack(q, bank, batch_size=64, float_path="mfma", chunk_bytes=100 * 4 * bank[0].size)     # streamed, same kernel
+    assert np.array_equal(is_, im) and np.array_equal(ds, dm)
+
+
 def test_medium_vs_c_oracle(gl, synth, coracle):
     case = synth.attack_case(51, 6000, 150, 150, 64)
     q = np.concatenate([case["pos"], case["neg"]])
