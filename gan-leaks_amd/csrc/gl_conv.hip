@@ -348,8 +348,7 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
     GL_REQUIRE(p.cols_pad % BN == 0 && p.cols <= p.cols_pad, "gather_conv: cols_pad=%d must be a multiple of %d", p.cols_pad, BN);
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv: grid too large");
     static bool attr_set = false;
-    static const int lds_pad = getenv("GL_CONV_LDS") ? atoi(getenv("GL_CONV_LDS")) : 0;   // occupancy experiment knob
-    const int lds_req = lds_pad > lds ? lds_pad : lds;
+    const int lds_req = lds;
     auto kern = gather_conv_kernel<WAVES_M, WAVES_N, TM, TN>;
     if (!attr_set) {
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_req));

@@ -29,12 +29,10 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 // WC x WP waves (channel direction x position direction), each owning 64 channels x 64 positions.
 //   <2,2>: 128 channels x 128 positions, 4 waves, 64 KiB LDS (2 workgroups per CU)
 //   <1,4>: 64 channels x 256 positions, 4 waves, 80 KiB LDS (2 workgroups per CU): layers with <= 64 output columns
-//   <2,4>: 128 channels x 256 positions, 8 waves, 96 KiB LDS (1 workgroup per CU): 25 % less staging per MFMA
-//   STAGES = 2: double buffer, __syncthreads() per slice (drains every load: prefetch distance one slice)
-//   STAGES = 3: ring of three slices, raw s_barrier + counted s_waitcnt vmcnt(N): the loads of slice k+2 are issued while
-//               slice k is computed, so a load has two slices (~1.5-3 k cycles) to land instead of one
-template <int WC, int WP, int STAGES>
-__global__ void __launch_bounds__(64 * WC * WP, STAGES == 3 && WC * WP == 4 ? 1 : 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
+// K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): a 128 x 256
+// tile with 8 waves, a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU.
+template <int WC, int WP>
+__global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
 #if __HIP_DEVICE_COMPILE__
     constexpr int HTC = 64 * WC, HTP = 64 * WP;        // tile: channels x positions
@@ -157,28 +155,11 @@ __global__ void __launch_bounds__(64 * WC * WP, STAGES == 3 && WC * WP == 4 ? 1 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_hi[j], acc[i][j], 0, 0, 0);
             }
     };
-    if constexpr (STAGES == 2) {
-        stage(0, smem);
-        for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();
-            if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF);
-            compute(smem + (kt & 1) * BUF);
-        }
-    } else {
-        // three-slice ring.  Per wave PW + PX LDS-DMA loads per slice; vmcnt counts them in issue order, so
-        // "all but the youngest PW + PX have landed" == "slice kt is in LDS" while slice kt+1 is still in flight.
-        stage(0, smem);
-        if (nk > 1) stage(1, smem + BUF);
-        int st = 0;                                   // ring slot of slice kt
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + PX) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();             // every wave's part of slice kt has landed; nobody still reads slice kt-1
-            const int st2 = st + 2 >= 3 ? st - 1 : st + 2;
-            if (kt + 2 < nk) stage(kt + 2, smem + st2 * BUF);   // overwrites the slot of slice kt-1
-            compute(smem + st * BUF);
-            st = st + 1 == 3 ? 0 : st + 1;
-        }
+    stage(0, smem);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF);
+        compute(smem + (kt & 1) * BUF);
     }
 
     // ---- epilogue.  C tile (16 x 16): column (position) = lane & 15, row (channel) = 4 * (lane >> 4) + reg.
@@ -261,7 +242,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 
 }  // namespace
 
-template <int WC, int WP, int STAGES>
+template <int WC, int WP>
 static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
     constexpr int HTC = 64 * WC, HTP = 64 * WP;
@@ -269,8 +250,8 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
     const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
     static bool attr_set = false;
-    constexpr int lds = STAGES * (HTC + HTP) * HBK_BYTES;
-    auto kern = gather_conv_h3_kernel<WC, WP, STAGES>;
+    constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
+    auto kern = gather_conv_h3_kernel<WC, WP>;
     if (!attr_set) {
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -301,13 +282,9 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE((uint64_t)p.cols_pad * p.ntaps * p.Cin * 4ull < 0xC0000000ull, "gather_conv_h3: packed weights too large");
     if (p.positions == 0) return GL_OK;
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
-    static const int variant = getenv("GL_H3_TILE") ? atoi(getenv("GL_H3_TILE")) : 0;   // tuning knob
-    if (variant == 1 && p.positions >= 65536) return launch_h3<2, 4, 2>(ctx, p, phases);   // 128 ch x 256 positions, 8 waves, double buffer
-    if (variant == 2 && p.positions >= 65536) return launch_h3<2, 4, 3>(ctx, p, phases);   // same tile, three-slice ring (144 KiB LDS)
-    if (variant == 3) return launch_h3<2, 2, 3>(ctx, p, phases);                          // 128 x 128, three-slice ring (96 KiB, 1 WG/CU)
     // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
-    if (p.cols <= 64 && variant != 4) return launch_h3<1, 4, 2>(ctx, p, phases);
-    return launch_h3<2, 2, 2>(ctx, p, phases);
+    if (p.cols <= 64) return launch_h3<1, 4>(ctx, p, phases);
+    return launch_h3<2, 2>(ctx, p, phases);
 }
 
 int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out)
