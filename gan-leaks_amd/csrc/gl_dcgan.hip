@@ -22,8 +22,9 @@ struct gl_dcgan {
     float *ident_scale, *ident_shift;   // epilogue constants (1, 0) for the layer-4 GEMM
     // optional self-attention on the output of layer 2 (VAEGAN: gan_models/vaegan/ops.py:86-120)
     bool have_att;
-    float *att_wq, *att_bq, *att_wk, *att_bk, *att_wv, *att_bv, att_gamma;
-    float *ws_att;
+    float *att_w, *att_wsplit, *att_bias, *att_ones, *att_scale_h3, att_gamma;   // [q | k | v] 1x1 convolutions as one GEMM
+    int att_cols, att_cols_pad, att_wexp;
+    float *ws_att, *ws_qkv;
     // split-fp16 path (gl_conv_h3.hip): weights in the split layout scaled by 2^wexp, epilogue constants folded for it
     int precision;             // 0 = fp32 MFMA (exact fp32 products), 1 = split-fp16 (three fp16 MFMAs per product, ~22-bit operands)
     float *wsplit[5];
@@ -61,69 +62,137 @@ int upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
 }
 
 
-// Self-attention (SAGAN style) over the T = 256 positions of a 16 x 16 map, per image
-// (gan_models/vaegan/ops.py:101-120):
-//   q = Wq x + bq, k = Wk x + bk  (C/8 channels), energy_ij = q_i . k_j, att = softmax_j(energy),
-//   out_i = sum_j att_ij (Wv x_j + bv) = Wv (sum_j att_ij x_j) + bv   (rows of att sum to 1),  y = gamma * out + x
-// One workgroup per image, one thread per position i.  Everything indexed by j or by a weight is wave-uniform
-// (scalar loads / LDS broadcast); per thread: q_i (C/8 regs), the running sum over j (C regs).
-template <int C>
-__global__ void __launch_bounds__(256) self_attention_kernel(const float *__restrict__ x, float *__restrict__ y, const float *__restrict__ wq,
-                                                             const float *__restrict__ bq, const float *__restrict__ wk, const float *__restrict__ bk,
-                                                             const float *__restrict__ wv, const float *__restrict__ bv, float gamma)
+// Self-attention (SAGAN style) over the T = 256 positions of a 16 x 16 map, per image (gan_models/vaegan/ops.py:101-120):
+//   q = Wq x + bq, k = Wk x + bk  (C/8 channels), v = Wv x + bv;  energy_ij = q_i . k_j, att = softmax_j(energy),
+//   out_i = sum_j att_ij v_j,  y = gamma * out + x
+// The three 1x1 convolutions run as ONE gather_conv GEMM with 2 C/8 + C columns (fp32 rows [position][q | k | v]); this
+// kernel is the attention proper on the fp32 matrix cores (v_mfma_f32_32x32x2f32: exact fp32 products).  One workgroup
+// of 8 waves per image, v (T x C) and kT (C/8 x T) staged in LDS, wave w owns the 32 query positions i of block w and
+// chains two GEMMs whose results are kept TRANSPOSED so that the accumulator layout of the first (column = lane & 31,
+// 16 rows per lane) is directly the B operand of the second -- no LDS round trip, no shuffles:
+//   E^T[j][i] = sum_d kT[d][j] q[i][d]        A = kT (LDS), B = q (8 registers)  -> per j-block a lane holds 16 j's of ONE i
+//   softmax over j: in-register max / sum + one shfl_xor(32) (the other 16 j's of each block live in the other lane half)
+//   O^T[c][i] = sum_j v[j][c] p[i][j]         A = v rows (LDS), B = the p registers
+// An MFMA contracts two k values per instruction, one from each lane half; WHICH two is free as long as A and B agree, and the
+// accumulator layout hands each half its own rows (4 fh + 8 g + r): that pairing is used for the second GEMM.
+// SPLIT: x and y in the split-fp16 activation layout (values * kActScale), otherwise fp32 NHWC.
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int C, bool SPLIT>
+__global__ void __launch_bounds__(512, 2) attention_core_kernel(const float *__restrict__ qkv, const char *__restrict__ x, char *__restrict__ y, float gamma,
+                                                                int *__restrict__ sat_flag)
 {
-    constexpr int DK = C / 8, T = 256;
-    __shared__ float ks[T][DK];
-    const int i = threadIdx.x;
-    const float *ximg = x + (int64_t)blockIdx.x * T * C;
-    const float *xi = ximg + (int64_t)i * C;
-    float q[DK], kk[DK];
-#pragma unroll
-    for (int d = 0; d < DK; ++d) { q[d] = bq[d]; kk[d] = bk[d]; }
-    for (int c = 0; c < C; c += 4) {
-        const float4 v = *reinterpret_cast<const float4 *>(xi + c);
-#pragma unroll
-        for (int d = 0; d < DK; ++d) {
-            q[d] = fmaf(wq[d * C + c + 0], v.x, q[d]); q[d] = fmaf(wq[d * C + c + 1], v.y, q[d]);
-            q[d] = fmaf(wq[d * C + c + 2], v.z, q[d]); q[d] = fmaf(wq[d * C + c + 3], v.w, q[d]);
-            kk[d] = fmaf(wk[d * C + c + 0], v.x, kk[d]); kk[d] = fmaf(wk[d * C + c + 1], v.y, kk[d]);
-            kk[d] = fmaf(wk[d * C + c + 2], v.z, kk[d]); kk[d] = fmaf(wk[d * C + c + 3], v.w, kk[d]);
-        }
+    constexpr int DK = C / 8, T = 256, QKV = 2 * DK + C, CB = C / 32;
+    extern __shared__ __attribute__((aligned(16))) float att_smem[];
+    float *vs = att_smem;                 // [T][C]
+    float *kT = att_smem + T * C;         // [DK][T]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fh = lane >> 5;
+    const float *base = qkv + (int64_t)blockIdx.x * T * QKV;
+    for (int idx = tid; idx < T * C / 4; idx += 512) {
+        const int j = idx / (C / 4), c4 = idx % (C / 4);
+        *reinterpret_cast<float4 *>(vs + j * C + c4 * 4) = *reinterpret_cast<const float4 *>(base + (int64_t)j * QKV + 2 * DK + c4 * 4);
     }
-#pragma unroll
-    for (int d = 0; d < DK; ++d) ks[i][d] = kk[d];
+    for (int idx = tid; idx < T * DK; idx += 512) {
+        const int j = idx / DK, d = idx % DK;
+        kT[d * T + j] = base[(int64_t)j * QKV + DK + d];
+    }
     __syncthreads();
+
+    const int i0 = wave * 32;
+    float qreg[DK / 2];
+#pragma unroll
+    for (int s = 0; s < DK / 2; ++s) qreg[s] = base[(int64_t)(i0 + frow) * QKV + 2 * s + fh];
+    // energies, transposed: e[jb][r] = energy(i = i0 + frow, j = jb * 32 + 4 fh + 8 (r >> 2) + (r & 3))
+    v16f e[T / 32];
+#pragma unroll
+    for (int jb = 0; jb < T / 32; ++jb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[jb][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < DK / 2; ++s) e[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kT[(2 * s + fh) * T + jb * 32 + frow], qreg[s], e[jb], 0, 0, 0);
+    }
     float m = -__builtin_inff();
-    for (int j = 0; j < T; ++j) {
-        float e = 0.0f;
 #pragma unroll
-        for (int d = 0; d < DK; ++d) e = fmaf(q[d], ks[j][d], e);
-        m = fmaxf(m, e);
-    }
-    float acc[C];
+    for (int jb = 0; jb < T / 32; ++jb)
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.0f;
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, e[jb][r]);
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
     float ssum = 0.0f;
-    for (int j = 0; j < T; ++j) {
-        float e = 0.0f;
 #pragma unroll
-        for (int d = 0; d < DK; ++d) e = fmaf(q[d], ks[j][d], e);
-        const float pj = __expf(e - m);
-        ssum += pj;
-        const float *xj = ximg + (int64_t)j * C;       // wave-uniform address
+    for (int jb = 0; jb < T / 32; ++jb)
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = fmaf(pj, xj[c], acc[c]);
+        for (int r = 0; r < 16; ++r) { e[jb][r] = __expf(e[jb][r] - m); ssum += e[jb][r]; }
+    ssum += __shfl_xor(ssum, 32, 64);
+    const float sc = gamma / ssum;          // 1 / sum and gamma are applied to the C results instead of the 256 probabilities
+    v16f o[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[cb][r] = 0.0f;
+#pragma unroll
+    for (int jb = 0; jb < T / 32; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float *vj = vs + (jb * 32 + 4 * fh + 8 * (r >> 2) + (r & 3)) * C + frow;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) o[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(vj[cb * 32], e[jb][r], o[cb], 0, 0, 0);
+        }
+    // o[cb][r] = O^T[c = cb * 32 + 4 fh + 8 (r >> 2) + (r & 3)][i = i0 + frow]: 4 consecutive channels per (cb, g = r >> 2)
+    const int64_t pos = (int64_t)blockIdx.x * T + i0 + frow;
+    bool saturated = false;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c0 = cb * 32 + 8 * g + 4 * fh;
+            if constexpr (SPLIT) {
+                typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+                const int64_t off = pos * C * 4 + (c0 >> 5) * 128 + (c0 & 31) * 2;
+                const v4h xh = *reinterpret_cast<const v4h *>(x + off), xl = *reinterpret_cast<const v4h *>(x + off + 64);
+                v4h hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float t = fmaf(sc * kActScale, o[cb][4 * g + r], (float)xh[r] + (float)xl[r]);   // stored values carry the factor kActScale
+                    const float cl = fminf(fmaxf(t, -65504.0f), 65504.0f);
+                    saturated |= (cl != t);
+                    hi[r] = (_Float16)cl;
+                    lo[r] = (_Float16)(cl - (float)hi[r]);
+                }
+                *reinterpret_cast<v4h *>(y + off) = hi;
+                *reinterpret_cast<v4h *>(y + off + 64) = lo;
+            } else {
+                const float4 xv = *reinterpret_cast<const float4 *>(x + (pos * C + c0) * 4);
+                float4 out;
+                out.x = fmaf(sc, o[cb][4 * g + 0], xv.x);
+                out.y = fmaf(sc, o[cb][4 * g + 1], xv.y);
+                out.z = fmaf(sc, o[cb][4 * g + 2], xv.z);
+                out.w = fmaf(sc, o[cb][4 * g + 3], xv.w);
+                *reinterpret_cast<float4 *>(y + (pos * C + c0) * 4) = out;
+            }
+        }
+    if (SPLIT && __any(saturated) && lane == 0) atomicAdd(sat_flag, 1);
+}
+
+template <int C>
+int launch_attention_core(gl_ctx *ctx, bool split, const float *qkv, const float *x, float *y, int64_t images, float gamma)
+{
+    constexpr int lds = (256 * C + (C / 8) * 256) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_core_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_core_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
     }
-    const float inv = 1.0f / ssum;
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] *= inv;
-    float *yi = y + ((int64_t)blockIdx.x * T + i) * C;
-    for (int co = 0; co < C; ++co) {
-        float o = bv[co];
-#pragma unroll
-        for (int c = 0; c < C; ++c) o = fmaf(wv[co * C + c], acc[c], o);
-        yi[co] = fmaf(gamma, o, xi[co]);
-    }
+    if (split)
+        hipLaunchKernelGGL((attention_core_kernel<C, true>), dim3((unsigned)images), dim3(512), lds, ctx->stream, qkv, reinterpret_cast<const char *>(x),
+                           reinterpret_cast<char *>(y), gamma, ctx->h3_sat);
+    else
+        hipLaunchKernelGGL((attention_core_kernel<C, false>), dim3((unsigned)images), dim3(512), lds, ctx->stream, qkv, reinterpret_cast<const char *>(x),
+                           reinterpret_cast<char *>(y), gamma, ctx->h3_sat);
+    GL_LAUNCH_CHECK();
+    return GL_OK;
 }
 
 int ensure_workspace(gl_dcgan *g, int64_t n)
@@ -138,7 +207,8 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
     (void)hipFree(g->ws_p);
     g->ws_p = nullptr;
     (void)hipFree(g->ws_att);
-    g->ws_att = nullptr;
+    (void)hipFree(g->ws_qkv);
+    g->ws_att = g->ws_qkv = nullptr;
     g->ws_chunk = 0;
     GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
     int hw = 16;
@@ -147,7 +217,10 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
         hw *= 4;
     }
     GL_HIP(hipMalloc((void **)&g->ws_p, (size_t)want * 32 * 32 * 16 * g->nc * 4));
-    GL_HIP(hipMalloc((void **)&g->ws_att, (size_t)want * 256 * g->cout[2] * 4));
+    if (g->have_att) {
+        GL_HIP(hipMalloc((void **)&g->ws_att, (size_t)want * 256 * g->cout[2] * 4));
+        GL_HIP(hipMalloc((void **)&g->ws_qkv, (size_t)want * 256 * (g->cout[2] + g->cout[2] / 4) * 4));
+    }
     g->ws_chunk = want;
     return GL_OK;
 }
@@ -181,9 +254,10 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->h3_dirty = true;
     for (int l = 0; l < 5; ++l) { g->wsplit[l] = nullptr; g->wexp[l] = 0; g->scale_h3[l] = g->shift_h3[l] = nullptr; }
     g->have_att = false;
-    g->att_wq = g->att_bq = g->att_wk = g->att_bk = g->att_wv = g->att_bv = nullptr;
+    g->att_w = g->att_wsplit = g->att_bias = g->att_ones = g->att_scale_h3 = nullptr;
     g->att_gamma = 0.0f;
-    g->ws_att = nullptr;
+    g->att_cols = g->att_cols_pad = g->att_wexp = 0;
+    g->ws_att = g->ws_qkv = nullptr;
     g->ident_scale = g->ident_shift = nullptr;
     {
         std::vector<float> one(16 * channels_img, 1.0f), zero(16 * channels_img, 0.0f);
@@ -206,7 +280,8 @@ int gl_dcgan_destroy(gl_dcgan *g)
     (void)hipFree(g->ws_p);
     (void)hipFree(g->ws_att);
     for (int l = 0; l < 5; ++l) { (void)hipFree(g->wsplit[l]); (void)hipFree(g->scale_h3[l]); (void)hipFree(g->shift_h3[l]); }
-    (void)hipFree(g->att_wq); (void)hipFree(g->att_bq); (void)hipFree(g->att_wk); (void)hipFree(g->att_bk); (void)hipFree(g->att_wv); (void)hipFree(g->att_bv);
+    (void)hipFree(g->att_w); (void)hipFree(g->att_wsplit); (void)hipFree(g->att_bias); (void)hipFree(g->att_ones); (void)hipFree(g->att_scale_h3);
+    (void)hipFree(g->ws_qkv);
     (void)hipFree(g->ident_scale);
     (void)hipFree(g->ident_shift);
     delete g;
@@ -340,13 +415,32 @@ int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const 
     GL_REQUIRE(g && wq && bq && wk && bk && wv && bv, "gl_dcgan_set_attention: NULL argument");
     const int C = g->cout[2], DK = C / 8;
     GL_REQUIRE(C == 64 || C == 128, "gl_dcgan_set_attention: attention width %d unsupported (64 or 128)", C);
-    int rc = upload(g->ctx, &g->att_wq, std::vector<float>(wq, wq + (size_t)DK * C));
-    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bq, std::vector<float>(bq, bq + DK));
-    if (rc == GL_OK) rc = upload(g->ctx, &g->att_wk, std::vector<float>(wk, wk + (size_t)DK * C));
-    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bk, std::vector<float>(bk, bk + DK));
-    if (rc == GL_OK) rc = upload(g->ctx, &g->att_wv, std::vector<float>(wv, wv + (size_t)C * C));
-    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bv, std::vector<float>(bv, bv + C));
+    // rows [q (DK) | k (DK) | v (C)] x K = C (one tap: the K order of gl_conv_k_index is the identity), padded to whole 128-column tiles
+    const int cols = 2 * DK + C, cols_pad = (int)gl_ceil_div(cols, 128) * 128;
+    std::vector<float> pk((size_t)cols_pad * C, 0.0f), bias(cols_pad, 0.0f);
+    std::copy(wq, wq + (size_t)DK * C, pk.begin());
+    std::copy(wk, wk + (size_t)DK * C, pk.begin() + (size_t)DK * C);
+    std::copy(wv, wv + (size_t)C * C, pk.begin() + (size_t)2 * DK * C);
+    std::copy(bq, bq + DK, bias.begin());
+    std::copy(bk, bk + DK, bias.begin() + DK);
+    std::copy(bv, bv + C, bias.begin() + 2 * DK);
+    float mx = 0.0f;
+    for (float v : pk) mx = std::fmax(mx, std::fabs(v));
+    int e = mx > 0.0f ? (int)std::floor(std::log2(8191.0f / mx)) : 0;
+    e = e > 30 ? 30 : (e < -30 ? -30 : e);
+    std::vector<float> split(pk.size());
+    gl_split_weights_host(pk.data(), (size_t)cols_pad, (size_t)C, std::ldexp(1.0f, e), split.data());
+    // split path: acc = 2^e * kActScale * (W x)  ->  true q / k / v = acc * 2^-e / kActScale + bias
+    int rc = upload(g->ctx, &g->att_w, pk);
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_wsplit, split);
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_bias, bias);
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_ones, std::vector<float>(cols_pad, 1.0f));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->att_scale_h3, std::vector<float>(cols_pad, std::ldexp(1.0f / kActScale, -e)));
     if (rc != GL_OK) return rc;
+    g->att_cols = cols;
+    g->att_cols_pad = cols_pad;
+    g->att_wexp = e;
+    if (!g->have_att) g->ws_chunk = 0;            // the attention workspaces are allocated with the others
     g->att_gamma = gamma;
     g->have_att = true;
     return GL_OK;
@@ -395,8 +489,7 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
     int rc = ensure_workspace(g, n);
     if (rc != GL_OK) return rc;
     const int64_t img_elems = (int64_t)g->nc * 64 * 64;
-    // split-fp16 path unless the caller asked for fp32 products or the (fp32) attention block sits in the stack
-    const bool h3 = g->precision == 1 && !g->have_att;
+    const bool h3 = g->precision == 1;
     if (h3) {
         rc = dcgan_prepare_h3(g);
         if (rc != GL_OK) return rc;
@@ -462,13 +555,17 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
             hw *= 2;
             if (l == 2 && g->have_att) {
                 GL_REQUIRE(hw == 16, "gl_dcgan_forward: attention expects a 16 x 16 map");
-                if (g->cout[2] == 128)
-                    hipLaunchKernelGGL(self_attention_kernel<128>, dim3((unsigned)m), dim3(256), 0, ctx->stream, g->ws_a[2], g->ws_att, g->att_wq, g->att_bq,
-                                       g->att_wk, g->att_bk, g->att_wv, g->att_bv, g->att_gamma);
-                else
-                    hipLaunchKernelGGL(self_attention_kernel<64>, dim3((unsigned)m), dim3(256), 0, ctx->stream, g->ws_a[2], g->ws_att, g->att_wq, g->att_bq,
-                                       g->att_wk, g->att_bk, g->att_wv, g->att_bv, g->att_gamma);
-                GL_LAUNCH_CHECK();
+                GlGatherConv a = {};
+                a.in = g->ws_a[2]; a.positions = m * 256; a.H = 16; a.W = 16; a.Cin = g->cout[2];
+                a.cols = g->att_cols; a.cols_pad = g->att_cols_pad; a.ntaps = 1; a.tap_dy[0] = 1; a.tap_dx[0] = 1;
+                a.out = g->ws_qkv; a.Ho = 16; a.Wo = 16; a.omul = 1; a.oy[0] = 0; a.ox[0] = 0;
+                a.shift = g->att_bias; a.cmod = g->att_cols_pad; a.act = 0; a.zero = ctx->zero_page;
+                if (h3) { a.wpack = g->att_wsplit; a.scale = g->att_scale_h3; rc = gl_launch_gather_conv_h3(ctx, a, 1); }
+                else { a.wpack = g->att_w; a.scale = g->att_ones; rc = gl_launch_gather_conv(ctx, a, 1); }
+                if (rc != GL_OK) return rc;
+                rc = g->cout[2] == 128 ? launch_attention_core<128>(ctx, h3, g->ws_qkv, g->ws_a[2], g->ws_att, m, g->att_gamma)
+                                       : launch_attention_core<64>(ctx, h3, g->ws_qkv, g->ws_a[2], g->ws_att, m, g->att_gamma);
+                if (rc != GL_OK) return rc;
             }
         }
         // layer 4: ConvT k4 s2 p1 -> 3 channels: scatter-form GEMM (48 columns) on the matrix cores,

@@ -41,6 +41,7 @@ class Generator:
         self._handle = None
         self._loaded = False
         self.power_iterations = 1
+        self._precision = 1
         self.chans = [self.z_dim, 8 * self.d, 4 * self.d, 2 * self.d, self.d, 3]
 
     @property
@@ -121,6 +122,11 @@ class Generator:
     def to(self, *a, **k):
         return self
 
+    def set_precision(self, mode):
+        """1 (default) = split-fp16 convolutions (three fp16 MFMAs per product), 0 = fp32 MFMA; the attention block is fp32 MFMA in both"""
+        check(self.ctx.lib.gl_dcgan_set_precision(self._ensure(), int(mode)))
+        self._precision = int(mode)
+
     def forward_device(self, x, want_f32=True, want_u8=False):
         if not self._loaded:
             raise RuntimeError("Generator: load_state_dict() has not been called")
@@ -133,6 +139,12 @@ class Generator:
         f32 = self.ctx.empty(shape, np.float32) if want_f32 else None
         u8 = self.ctx.empty(shape, np.uint8) if want_u8 else None
         check(self.ctx.lib.gl_dcgan_forward(self._handle, _p(z.ptr), n, _p(f32.ptr if f32 else 0), _p(u8.ptr if u8 else 0)))
+        if self._precision == 1 and self.ctx.h3_saturations() > 0:
+            # an activation left the fp16 range of the split layout: redo this call (same spectral-norm state) with fp32 products
+            import warnings
+            warnings.warn("split-fp16 generator path saturated for these weights; falling back to fp32 MFMA products")
+            self.set_precision(0)
+            check(self.ctx.lib.gl_dcgan_forward(self._handle, _p(z.ptr), n, _p(f32.ptr if f32 else 0), _p(u8.ptr if u8 else 0)))
         return f32, u8
 
     def forward(self, input):

@@ -10,11 +10,15 @@ import gpu_common  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-def test_vaegan_generator_two_forwards(synth, golden_dir):
+@pytest.mark.parametrize("precision", [1, 0])
+def test_vaegan_generator_two_forwards(precision, synth, golden_dir):
+    """precision 1 (default): split-fp16 convolutions; 0: fp32 MFMA.  The attention block (one q|k|v GEMM + the fp32-MFMA
+    attention kernel) is shared."""
     from ganleaks_amd.gan_models.vaegan.train import Generator
     g = np.load(os.path.join(golden_dir, "vaegan_gen.npz"))
     gen = Generator(100, 64)
     assert "matched" in gen.load_state_dict(synth.vaegan_state_dict(777, 100, 64))
+    gen.set_precision(precision)
     z = synth.latent(4, 6)
     out1 = gen.eval()(z)
     assert out1.shape == (6, 3, 64, 64)
@@ -25,6 +29,7 @@ def test_vaegan_generator_two_forwards(synth, golden_dir):
     assert e2 < 5e-5, e2
     assert np.abs(gen.state_dict()["deconv1.module.weight_u"] - g["u1"]).max() < 1e-5
     assert np.abs(gen.state_dict()["deconv4.module.weight_v"] - g["v4"]).max() < 1e-5
+    assert gen._precision == precision                  # no saturation fallback happened
 
 
 def test_vaegan_oracle_and_chunks(synth):
@@ -42,3 +47,7 @@ def test_vaegan_oracle_and_chunks(synth):
     gen2 = Generator(64, 32)
     gen2.load_state_dict(sd)
     assert np.array_equal(gen2(z), out)
+    gen3 = Generator(64, 32)
+    gen3.load_state_dict(sd)
+    gen3.set_precision(0)
+    assert np.abs(gen3(z) - out).max() < 2e-5
