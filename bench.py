@@ -54,6 +54,7 @@ def main():
                     help="generator arithmetic: 1 = split-fp16 (three fp16 MFMAs per product, default), 0 = fp32 MFMA")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal: several ranks may then share one GPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="stop the CPU baseline after this many seconds (at least 8 queries are timed)")
     ap.add_argument("--feat-rows", default="fp16", choices=["fp16", "split"],
                     help="l2-lpips only: rows of the nearest-neighbour search: fp16 = one half per LPIPS value (gl_feat_knn_h1, default), "
                          "split = hi + lo halves of everything (gl_feat_knn)")
@@ -337,7 +338,11 @@ def main():
             d_, i_ = torch_port.custom_knn(bank_f, q_f[k], torch_port.l2_loss, B)
             cd.append(d_)
             ci.append(i_)
+            if k + 1 >= 8 and time.perf_counter() - tc > args.cpu_seconds:      # bounded sample: host speed varies a lot between boxes
+                break
         cpu_s = time.perf_counter() - tc
+        nq_cpu = len(cd)
+        sel = sel[:nq_cpu]
         cpu = {"value": round(nq_cpu / cpu_s, 4), "unit": "query-images/s", "cores": int(torch.get_num_threads()), "kind": "port",
                "sample": "%d of the %d queries x the full %d-sample bank, BATCH_SIZE %d, PyTorch-CPU restatement of fbb.custom_knn "
                          "(oracle/torch_port.py); bank search only, the CPU does not run the generator" % (nq_cpu, Q, n_loc, B),

@@ -26,16 +26,18 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 
 constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi + 64 B lo
 
-// WC x WP waves (channel direction x position direction), each owning 64 channels x 64 positions.
-//   <2,2>: 128 channels x 128 positions, 4 waves, 64 KiB LDS (2 workgroups per CU)
-//   <1,4>: 64 channels x 256 positions, 4 waves, 80 KiB LDS (2 workgroups per CU): layers with <= 64 output columns
+// WC x WP waves (channel direction x position direction), each owning TC x TP tiles of 16 x 16:
+//   <2,2,4,4>: 128 channels x 128 positions, 4 waves of 64 x 64, 64 KiB LDS (2 workgroups per CU)
+//   <1,4,4,4>: 64 channels x 256 positions, 4 waves, 80 KiB LDS (2 workgroups per CU): layers with <= 64 output columns
+//   <2,4,8,4>: 256 channels x 256 positions, 8 waves of 128 x 64, 128 KiB LDS (1 workgroup per CU): wide layers of large passes
 // K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): a 128 x 256
-// tile with 8 waves, a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU.
-template <int WC, int WP>
+// tile with 8 waves of 64 x 64, 128 x 512 / 128 x 256 tiles for 128-column layers, a ring of three slices with counted
+// s_waitcnt vmcnt(N), 4 workgroups per CU.
+template <int WC, int WP, int TC = 4, int TP = 4>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
 #if __HIP_DEVICE_COMPILE__
-    constexpr int HTC = 64 * WC, HTP = 64 * WP;        // tile: channels x positions
+    constexpr int HTC = 16 * TC * WC, HTP = 16 * TP * WP;        // tile: channels x positions (a wave owns TC x TP tiles of 16 x 16)
     constexpr int W_BYTES = HTC * HBK_BYTES, X_BYTES = HTP * HBK_BYTES, BUF = W_BYTES + X_BYTES;
     constexpr int NW = WC * WP;
     constexpr int PW = (HTC / 8) / NW, PX = (HTP / 8) / NW;   // 1-KiB staging pieces per wave and slice
@@ -127,29 +129,33 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         }
     };
 
-    v4f acc[4][4];
+    v4f acc[TC][TP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TP; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fk = lane >> 4;
     auto compute = [&](const char *cur) {
-        const char *lw = cur + (wc * 64) * HBK_BYTES;
-        const char *lx = cur + W_BYTES + (wp_ * 64) * HBK_BYTES;
-        v8h w_hi[4], w_lo[4], x_hi[4], x_lo[4];
+        const char *lw = cur + (wc * 16 * TC) * HBK_BYTES;
+        const char *lx = cur + W_BYTES + (wp_ * 16 * TP) * HBK_BYTES;
+        v8h w_hi[TC], w_lo[TC], x_hi[TP], x_lo[TP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TC; ++i) {
             const int r = i * 16 + frow;
             w_hi[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
             w_lo[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
-            x_hi[i] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
-            x_lo[i] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < TP; ++j) {
+            const int r = j * 16 + frow;
+            x_hi[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
+            x_lo[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[i], x_hi[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_lo[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_hi[j], acc[i][j], 0, 0, 0);
@@ -177,21 +183,21 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         orow[tid] = o;
     }
     __syncthreads();
-    int o4[4];
+    int o4[TP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o4[j] = orow[wp_ * 64 + j * 16 + frow];
+    for (int j = 0; j < TP; ++j) o4[j] = orow[wp_ * 16 * TP + j * 16 + frow];
     const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
     const float neg_slope = p.act == 2 ? 0.2f : 1.0f;
     bool saturated = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ch = c0 + wc * 64 + i * 16 + 4 * fk;          // first of this lane's 4 consecutive channels
+    for (int i = 0; i < TC; ++i) {
+        const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;     // first of this lane's 4 consecutive channels
         if (ch >= p.cols) continue;                             // cols is a multiple of 4 (host-checked)
         float sc[4], sh[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sc[r] = p.scale[(ch + r) % p.cmod]; sh[r] = p.shift[(ch + r) % p.cmod]; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TP; ++j) {
             const int o = o4[j];
             if (o < 0) continue;
             float v[4];
@@ -242,16 +248,16 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 
 }  // namespace
 
-template <int WC, int WP>
+template <int WC, int WP, int TC = 4, int TP = 4>
 static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
-    constexpr int HTC = 64 * WC, HTP = 64 * WP;
+    constexpr int HTC = 16 * TC * WC, HTP = 16 * TP * WP;
     const int64_t m_tiles = gl_ceil_div(p.positions, HTP);
     const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
     static bool attr_set = false;
     constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
-    auto kern = gather_conv_h3_kernel<WC, WP>;
+    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP>;
     if (!attr_set) {
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -284,6 +290,9 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
     // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
     if (p.cols <= 64) return launch_h3<1, 4>(ctx, p, phases);
+    // wide layers with enough work to fill the chip: 256 channels x 256 positions, 8 waves of 128 x 64 (24 LDS fragment reads per 96
+    // MFMAs instead of 16 per 48, half the staging per MFMA): +7 % on the DCGAN stack (A/B on one device, profiles/r01/README.md)
+    if (p.cols % 256 == 0 && gl_ceil_div(p.positions, 256) * (p.cols / 256) * phases >= 1024) return launch_h3<2, 4, 8, 4>(ctx, p, phases);
     return launch_h3<2, 2>(ctx, p, phases);
 }
 
