@@ -106,6 +106,7 @@ SIGNATURES = {
     "gl_lpips_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_lpips_features_f32": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_feat_knn": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gl_fbb_knn_lpips_host": (_i, [_p, _p, _p, _i64, _p, _i64, _i, _i, _i64, _i64, _p, _p]),
     "gl_rows_split_dim": (_i64, [_i64]),
     "gl_rows_split_f32": (_i, [_p, _p, _i64, _i64, _p, _p, _p]),
     "gl_rows_knn_split": (_i, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p]),

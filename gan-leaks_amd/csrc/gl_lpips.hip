@@ -1127,4 +1127,61 @@ int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const floa
     return GL_OK;
 }
 
+/* custom_knn with Loss('l2-lpips') for whole query sets held in HOST memory (the reference's default fbb distance, attack_models/fbb.py:148),
+ * as one call for foreign callers: BATCH_SIZE truncation (fbb.py:77), search rows, the bank streamed through HBM in chunks so that
+ * at most ~max_device_bytes of feature rows are resident (0 = 64 GiB). */
+int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host, int64_t n_bank, const uint8_t *queries_u8_host, int64_t nq, int H, int W,
+                          int64_t batch_size, int64_t max_device_bytes, float *dist_host, int64_t *idx_host)
+{
+    GL_REQUIRE(ctx && l && l->ctx == ctx && n_bank >= 0 && nq >= 0 && batch_size > 0, "gl_fbb_knn_lpips_host: bad argument");
+    const int64_t K1 = gl_lpips_search_dim(H, W);
+    GL_REQUIRE(K1 > 0, "gl_fbb_knn_lpips_host: H, W must be multiples of 16, got %dx%d", H, W);
+    const int64_t n_eff = (n_bank / batch_size) * batch_size;
+    if (n_eff == 0) {
+        gl_set_error("gl_fbb_knn_lpips_host: bank of %lld rows holds no full batch of %lld (reference: ValueError at fbb.py:83)", (long long)n_bank, (long long)batch_size);
+        return GL_ERR_EMPTY_BANK;
+    }
+    if (nq == 0) return GL_OK;
+    GL_REQUIRE(bank_u8_host && queries_u8_host && dist_host && idx_host, "gl_fbb_knn_lpips_host: NULL host pointer");
+    const int64_t D = 3ll * H * W, row = K1 * 2;
+    const int64_t budget = max_device_bytes > 0 ? max_device_bytes : (64ll << 30);
+    GL_REQUIRE(nq * row <= budget, "gl_fbb_knn_lpips_host: %lld query rows of %lld bytes exceed the device budget; call with fewer queries", (long long)nq, (long long)row);
+    int64_t chunk = budget / row;
+    if (chunk > n_eff) chunk = n_eff;
+    if (chunk < 1) chunk = 1;
+    uint8_t *raw = nullptr;
+    void *qV = nullptr, *bV = nullptr;
+    float *qn = nullptr, *bn = nullptr, *dist = nullptr;
+    uint64_t *keys = nullptr;
+    int64_t *idx = nullptr;
+    int rc = GL_OK;
+#define GL_TRY(e) do { rc = (e); if (rc != GL_OK) goto done; } while (0)
+    GL_TRY(gl_malloc(ctx, (size_t)((chunk > nq ? chunk : nq) * D), (void **)&raw));
+    GL_TRY(gl_malloc(ctx, (size_t)(nq * row), &qV));
+    GL_TRY(gl_malloc(ctx, (size_t)(chunk * row), &bV));
+    GL_TRY(gl_malloc(ctx, (size_t)nq * 4, (void **)&qn));
+    GL_TRY(gl_malloc(ctx, (size_t)chunk * 4, (void **)&bn));
+    GL_TRY(gl_malloc(ctx, (size_t)nq * 8, (void **)&keys));
+    GL_TRY(gl_malloc(ctx, (size_t)nq * 4, (void **)&dist));
+    GL_TRY(gl_malloc(ctx, (size_t)nq * 8, (void **)&idx));
+    GL_TRY(gl_memcpy_h2d(ctx, raw, queries_u8_host, (size_t)(nq * D)));
+    GL_TRY(gl_lpips_search_features_u8(l, raw, nq, H, W, 0, qV, qn));
+    GL_TRY(gl_keys_init(ctx, keys, nq));
+    for (int64_t lo = 0; lo < n_eff; lo += chunk) {
+        const int64_t m = n_eff - lo < chunk ? n_eff - lo : chunk;
+        GL_TRY(gl_ctx_sync(ctx));                                  // raw is reused
+        GL_TRY(gl_memcpy_h2d(ctx, raw, bank_u8_host + lo * D, (size_t)(m * D)));
+        GL_TRY(gl_lpips_search_features_u8(l, raw, m, H, W, 1, bV, bn));
+        GL_TRY(gl_feat_knn_h1(ctx, bV, bn, m, lo, qV, qn, nq, K1, keys));
+    }
+    GL_TRY(gl_keys_unpack_f32(ctx, keys, nq, dist, idx));
+    GL_TRY(gl_memcpy_d2h(ctx, dist_host, dist, (size_t)nq * 4));
+    GL_TRY(gl_memcpy_d2h(ctx, idx_host, idx, (size_t)nq * 8));
+#undef GL_TRY
+done:
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(raw); (void)hipFree(qV); (void)hipFree(bV); (void)hipFree(qn); (void)hipFree(bn); (void)hipFree(keys); (void)hipFree(dist); (void)hipFree(idx);
+    return rc;
+}
+
 }  // extern "C"

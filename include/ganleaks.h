@@ -253,6 +253,11 @@ int64_t gl_rows_split_dim(int64_t d);
 int gl_rows_split_f32(gl_ctx *ctx, const float *rows_f32_dev, int64_t n, int64_t d, void *V_dev, float *norms_dev, float *scales_dev);
 int gl_rows_knn_split(gl_ctx *ctx, const void *bank_V_dev, const float *bank_norm_dev, const float *bank_scale_dev, int64_t n_rows, int64_t index_base,
                       const void *query_V_dev, const float *query_norm_dev, const float *query_scale_dev, int64_t nq, int64_t d, uint64_t *keys_dev);
+/* custom_knn with Loss('l2-lpips') -- the reference's default fbb distance (attack_models/fbb.py:148) -- for host-resident 8-bit images in ONE call:
+ * BATCH_SIZE truncation (fbb.py:77), search rows, the bank streamed through HBM so that about max_device_bytes (0 = 64 GiB) of feature rows are
+ * resident at a time.  Returns GL_ERR_EMPTY_BANK where the reference raises at fbb.py:83. */
+int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host, int64_t n_bank, const uint8_t *queries_u8_host, int64_t nq, int H, int W,
+                          int64_t batch_size, int64_t max_device_bytes, float *dist_host, int64_t *idx_host);
 /* Loss('l2-lpips').forward: per row, out_lpips = LPIPS and out_l2 = mean((y-x)^2) between V_hat[i] and V_gt[b_gt == 1 ? 0 : i];
  * K_lp = K - 3 H W is the length of the LPIPS part of V */
 int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,

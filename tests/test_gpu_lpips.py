@@ -144,6 +144,30 @@ def test_larger_images(gl, synth, model, lin, oracle):
     assert np.array_equal(is_, res["fp16"][1]) and np.array_equal(ds, res["fp16"][0])
 
 
+def test_host_one_call_lpips_abi(gl, synth, model):
+    """gl_fbb_knn_lpips_host straight through ctypes (what a non-Python host would bind), resident and streamed in 3 chunks"""
+    import ctypes
+    from ganleaks_amd import _lib
+    lib = _lib.load()
+    ctx = gl.Context.get()
+    case = synth.attack_case(93, 70, 5, 4, 32, sigma=20.0)
+    bank = np.ascontiguousarray(case["bank"])
+    q = np.ascontiguousarray(np.concatenate([case["pos"], case["neg"]]))
+    d0, i0 = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=model)
+    p = ctypes.c_void_p
+    row = 2 * int(lib.gl_lpips_search_dim(32, 32))
+    for budget in (0, 30 * row):
+        dist = np.empty(len(q), np.float32)
+        idx = np.empty(len(q), np.int64)
+        rc = lib.gl_fbb_knn_lpips_host(ctx.handle, model._handle, bank.ctypes.data_as(p), len(bank), q.ctypes.data_as(p), len(q), 32, 32, 16, budget,
+                                       dist.ctypes.data_as(p), idx.ctypes.data_as(p))
+        assert rc == 0, lib.gl_last_error()
+        assert np.array_equal(idx, i0) and np.array_equal(dist, d0)
+    rc = lib.gl_fbb_knn_lpips_host(ctx.handle, model._handle, bank.ctypes.data_as(p), 10, q.ctypes.data_as(p), len(q), 32, 32, 16, 0, dist.ctypes.data_as(p),
+                                   idx.ctypes.data_as(p))
+    assert rc == -5 and b"no full batch" in lib.gl_last_error()
+
+
 def test_search_rows_multi_tile(gl, synth, model):
     """600 bank rows x 300 queries: several 256 x 256 tiles with ragged edges in both directions.  No CPU oracle at this size
     (VGG16 in fp64 takes minutes); the split-row search, itself pinned to the oracle above, is the reference."""
