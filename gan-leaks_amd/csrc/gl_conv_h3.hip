@@ -31,7 +31,8 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 //   <1,4,4,4>: 64 channels x 256 positions, 4 waves, 80 KiB LDS (2 workgroups per CU): layers with <= 64 output columns
 //   <2,4,8,4>: 256 channels x 256 positions, 8 waves of 128 x 64, 128 KiB LDS (1 workgroup per CU): wide layers of large passes
 // K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): a 128 x 256
-// tile with 8 waves of 64 x 64, 128 x 512 / 128 x 256 tiles for 128-column layers, a ring of three slices with counted
+// tile with 8 waves of 64 x 64, 256 x 256 with 4 waves of 128 x 128 (1 wave per SIMD), 128 x 512 / 128 x 256 tiles for 128-column
+// layers, a ring of three slices with counted
 // s_waitcnt vmcnt(N), 4 workgroups per CU.
 template <int WC, int WP, int TC = 4, int TP = 4>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
