@@ -80,6 +80,26 @@ def test_loss_forward_and_custom_knn(name, gl, synth, model, oracle, golden_dir)
         assert i == int(g["idx"][k]) and abs(d - float(g["dist"][k])) < 5e-6
 
 
+def test_perceptual_loss_drop_in(gl, synth, model, golden_dir):
+    """lpips_pytorch.PerceptualLoss(model='net-lin', net='vgg').forward(pred, target) -> [N,1,1,1], the surface utils.py:157,171 uses"""
+    import torch
+    from ganleaks_amd.attack_models import lpips_pytorch as ps
+    g = np.load(os.path.join(golden_dir, "lpips_res32.npz"))
+    bank, q = _case(g, synth)
+    loss = ps.PerceptualLoss(model='net-lin', net='vgg', use_gpu=True, lpips_model=model)
+    bs = int(g["batch_size"])
+    pred = 2.0 * (bank[:bs].astype(np.float32) / 255.0) - 1.0
+    target = 2.0 * (q[:1].astype(np.float32) / 255.0) - 1.0
+    d = loss.forward(pred, target)
+    assert d.shape == (bs, 1, 1, 1) and d.dtype == np.float32
+    assert np.abs(d.reshape(-1) - g["lpips"][0, :bs]).max() < 5e-6
+    dt = loss(torch.from_numpy((pred + 1) / 2), torch.from_numpy((target + 1) / 2), normalize=True)       # [0,1] images
+    assert isinstance(dt, torch.Tensor) and tuple(dt.shape) == (bs, 1, 1, 1)
+    assert np.abs(dt.numpy().reshape(-1) - g["lpips"][0, :bs]).max() < 2e-5      # (x+1)/2 and back is not exact in fp32
+    with pytest.raises(NotImplementedError):
+        ps.PerceptualLoss(model='net', net='alex')
+
+
 def test_vs_fp64_oracle_ragged_and_shards(gl, synth, model, lin, oracle):
     """sizes that do not fill tiles; off-lattice float images; shard merge"""
     import lpips_oracle
