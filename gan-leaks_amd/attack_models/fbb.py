@@ -82,13 +82,33 @@ def _cached_bank(syn_imgs, n_rows, loss):
     return _bank_cache["bank"]
 
 
+def _custom_knn_foreign_loss(syn_imgs, sample, loss, args):
+    """a caller-supplied distance function: the reference's loop as written (fbb.py:77-88).  The callable does the arithmetic
+    (wherever it likes); only Loss instances are routed to the device kernels."""
+    dists = []
+    for i in range(len(syn_imgs) // args.BATCH_SIZE):
+        x_batch = syn_imgs[i * args.BATCH_SIZE:(i + 1) * args.BATCH_SIZE]
+        x_gt = sample.unsqueeze(0) if hasattr(sample, "unsqueeze") else np.asarray(sample)[None]
+        d = loss(x_batch, x_gt)
+        if hasattr(d, "detach"):
+            d = d.detach().cpu().numpy()
+        dists.append(np.asarray(d).reshape(-1))
+    if not dists:
+        raise ValueError("torch.cat(): expected a non-empty list of Tensors")   # what fbb.py:83 raises
+    dists = np.concatenate(dists)
+    k = int(np.argmin(dists))                                                  # first minimum, as torch.min (fbb.py:86)
+    return float(dists[k]), k
+
+
 def custom_knn(syn_imgs, sample, loss, args):
     """attack_models/fbb.py:73-88.  syn_imgs [N,C,H,W], sample [C,H,W], loss = Loss(...) instance,
     args.BATCH_SIZE.  Returns (min distance as python float, index as python int); only the first
     (N // BATCH_SIZE) * BATCH_SIZE bank samples take part, first index wins ties."""
     distance = getattr(loss, "distance", None)
     if distance is None:
-        raise TypeError("loss must be a ganleaks_amd Loss instance (its .distance selects the kernel)")
+        if not callable(loss):
+            raise TypeError("loss must be a ganleaks_amd Loss instance or a callable(x_batch, x_gt) -> [B]")
+        return _custom_knn_foreign_loss(syn_imgs, sample, loss, args)
     n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
     if n_rows == 0:
         raise ValueError("torch.cat(): expected a non-empty list of Tensors")   # what fbb.py:83 raises

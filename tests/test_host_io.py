@@ -106,3 +106,26 @@ def test_generator_state_dict_validation_without_gpu(gl):
     if gl.device_count() == 0:
         with pytest.raises(gl.GanLeaksError):
             g.load_state_dict(gl.synth.dcgan_state_dict(1))
+
+
+def test_custom_knn_with_a_foreign_loss_callable(gl, oracle):
+    """custom_knn(syn_imgs, sample, loss, args) accepts any callable like the reference (fbb.py:73-88); only Loss instances go to the device"""
+    import types
+    from ganleaks_amd.attack_models.fbb import custom_knn
+    rng = np.random.default_rng(3)
+    bank = rng.uniform(-1, 1, size=(75, 3, 8, 8)).astype(np.float32)
+    q = rng.uniform(-1, 1, size=(3, 8, 8)).astype(np.float32)
+    bank[40] = q
+    bank[10] = q                                                   # a tie: the first index wins
+    args = types.SimpleNamespace(BATCH_SIZE=32)
+    d, i = custom_knn(bank, q, lambda x, y: ((y - x) ** 2).mean(axis=(1, 2, 3)), args)
+    assert isinstance(d, float) and isinstance(i, int) and (d, i) == (0.0, 10)
+    od, oi = oracle.custom_knn_literal(bank, q, 32)
+    assert (od, oi) == (d, i)
+    import torch
+    d2, i2 = custom_knn(torch.from_numpy(bank), torch.from_numpy(q), lambda x, y: torch.mean((y - x) ** 2, dim=[1, 2, 3]), args)
+    assert (d2, i2) == (0.0, 10)
+    with pytest.raises(ValueError):
+        custom_knn(bank[:31], q, lambda x, y: ((y - x) ** 2).mean(axis=(1, 2, 3)), args)
+    with pytest.raises(TypeError):
+        custom_knn(bank, q, 3.0, args)
