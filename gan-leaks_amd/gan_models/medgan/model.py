@@ -63,6 +63,12 @@ class _Base:
     def to(self, *a, **k):
         return self
 
+    def cuda(self, *a, **k):                 # vaegan/sample.py:36 calls .cuda(); the weights already live on the device
+        return self
+
+    def train(self, mode=True):              # inference only: BatchNorm always uses its running statistics
+        return self
+
 
 class Generator(_Base):
     def __init__(self, z_dim, hidden_size, ctx=None):

@@ -101,6 +101,12 @@ class Generator:
     def to(self, *a, **k):
         return self
 
+    def cuda(self, *a, **k):                 # vaegan/sample.py:36 calls .cuda(); the weights already live on the device
+        return self
+
+    def train(self, mode=True):              # inference only: BatchNorm always uses its running statistics
+        return self
+
     def set_precision(self, mode):
         """1 (default) = split-fp16 convolutions, 0 = fp32 MFMA"""
         check(self.ctx.lib.gl_pggan_set_precision(self._ensure(), int(mode)))
@@ -163,6 +169,12 @@ class stackGenerators:
         return self
 
     def to(self, *a, **k):
+        return self
+
+    def cuda(self, *a, **k):                 # vaegan/sample.py:36 calls .cuda(); the weights already live on the device
+        return self
+
+    def train(self, mode=True):              # inference only: BatchNorm always uses its running statistics
         return self
 
     def forward(self, x, steps, alpha, i):

@@ -122,6 +122,12 @@ class Generator:
     def to(self, *a, **k):
         return self
 
+    def cuda(self, *a, **k):                 # vaegan/sample.py:36 calls .cuda(); the weights already live on the device
+        return self
+
+    def train(self, mode=True):              # inference only: BatchNorm always uses its running statistics
+        return self
+
     def set_precision(self, mode):
         """1 (default) = split-fp16 convolutions (three fp16 MFMAs per product), 0 = fp32 MFMA; the attention block is fp32 MFMA in both"""
         check(self.ctx.lib.gl_dcgan_set_precision(self._ensure(), int(mode)))
