@@ -171,3 +171,26 @@ def test_split_path_saturation_falls_back(gl, synth, oracle):
     ref = oracle.dcgan_generator_forward(sd, z)
     assert np.abs(out - ref).max() < 5e-5
     assert g._precision == 0
+
+
+def test_large_pass_tiles_match_small_pass_tiles(gl, synth):
+    """wide layers of large passes run on 256 x 256 tiles (8 waves of 128 x 64), small passes on 128 x 128: every output element sums
+    its K slices in the same order either way, so the images must be bit-identical -- DCGAN (2050 images: ragged last tile) and
+    PGGAN with the fused x2 upsampling (256 channels, 32 x 32, 260 images)"""
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    from ganleaks_amd.gan_models.pggan.model_torch import Generator as PGGAN
+    g = Generator(100, 3, 64)
+    g.load_state_dict(synth.dcgan_state_dict(1234))
+    z = synth.latent(9, 2050)
+    big_f, big_u = g.forward_device(z, True, True)
+    big_f, big_u = big_f.numpy(), big_u.numpy()
+    g.set_chunk(128)
+    small_f, small_u = g.forward_device(z, True, True)
+    assert np.array_equal(small_f.numpy(), big_f) and np.array_equal(small_u.numpy(), big_u)
+    p = PGGAN(128, 256, 3)
+    p.load_state_dict(synth.pggan_state_dict(3, 128, 256))
+    zp = synth.latent(10, 260, 128)
+    big = p.forward_device(zp, 3, 1.0, True, False)[0].numpy()
+    p.set_chunk(20)
+    small = p.forward_device(zp, 3, 1.0, True, False)[0].numpy()
+    assert big.shape == (260, 3, 32, 32) and np.array_equal(small, big)
