@@ -84,7 +84,8 @@ def _cached_bank(syn_imgs, n_rows, loss):
 
 def _custom_knn_foreign_loss(syn_imgs, sample, loss, args):
     """a caller-supplied distance function: the reference's loop as written (fbb.py:77-88).  The callable does the arithmetic
-    (wherever it likes); only Loss instances are routed to the device kernels."""
+    (wherever it likes).  This is not a fallback of the device path: Loss instances -- everything the reference itself passes --
+    never reach it."""
     dists = []
     for i in range(len(syn_imgs) // args.BATCH_SIZE):
         x_batch = syn_imgs[i * args.BATCH_SIZE:(i + 1) * args.BATCH_SIZE]
