@@ -26,6 +26,13 @@ struct gl_dcgan {
     int att_cols, att_cols_pad, att_wexp;
     float *ws_att, *ws_qkv;
     // split-fp16 path (gl_conv_h3.hip): weights in the split layout scaled by 2^wexp, epilogue constants folded for it
+    // optional spectral normalisation of layers 0..3 (VAEGAN: gan_models/vaegan/ops.py:23-75): w_bar as [C_in][C_out * 16], the power-iteration
+    // state u [C_in], v [C_out * 16] and gamma / sqrt(var + eps) per output channel stay on the device; every forward advances u, v and
+    // rewrites the epilogue scale as bn_scale / sigma
+    bool have_sn[4];
+    float *sn_w[4], *sn_u[4], *sn_v[4], *sn_wv[4], *sn_bns[4];
+    int sn_iters;
+    bool sn_hold;              // next forward(s) reuse the current sigma (a re-run of the same call)
     int precision;             // 0 = fp32 MFMA (exact fp32 products), 1 = split-fp16 (three fp16 MFMAs per product, ~22-bit operands)
     float *wsplit[5];
     int wexp[5];
@@ -195,6 +202,70 @@ int launch_attention_core(gl_ctx *ctx, bool split, const float *qkv, const float
     return GL_OK;
 }
 
+// ---- spectral normalisation on the device (SpectralNorm._update_u_v, gan_models/vaegan/ops.py:32-44), W = w_bar.view(H, -1) ----
+// v_raw[j] = sum_i W[i][j] u[i]
+__global__ void __launch_bounds__(256) sn_wt_u_kernel(const float *__restrict__ W, const float *__restrict__ u, int H, int Wd, float *__restrict__ out)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Wd) return;
+    float acc = 0.0f;
+    for (int i = 0; i < H; ++i) acc = fmaf(W[(int64_t)i * Wd + j], u[i], acc);
+    out[j] = acc;
+}
+
+__device__ __forceinline__ double block_sum256(double v, double *red)
+{
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const double s = red[0];
+    __syncthreads();
+    return s;
+}
+
+// x <- x / (|x| + 1e-12)   (l2normalize, ops.py:19-20); one workgroup
+__global__ void __launch_bounds__(256) sn_normalize_kernel(float *__restrict__ x, int n)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i] * (double)x[i];
+    const float inv = 1.0f / ((float)sqrt(block_sum256(s, red)) + 1e-12f);
+    for (int i = threadIdx.x; i < n; i += 256) x[i] *= inv;
+}
+
+// wv[i] = sum_j W[i][j] v[j]; one workgroup per row
+__global__ void __launch_bounds__(256) sn_w_v_kernel(const float *__restrict__ W, const float *__restrict__ v, int Wd, float *__restrict__ out)
+{
+    __shared__ double red[256];
+    const float *row = W + (int64_t)blockIdx.x * Wd;
+    float acc = 0.0f;
+    for (int j = threadIdx.x; j < Wd; j += 256) acc = fmaf(row[j], v[j], acc);
+    const double s = block_sum256((double)acc, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
+}
+
+// u = wv / (|wv| + 1e-12);  with `last`: sigma = u . wv, scale[c] = bn_scale[c] / sigma (and the split-path copy * 2^-wexp).  One workgroup.
+__global__ void __launch_bounds__(256) sn_finish_kernel(const float *__restrict__ wv, int H, float *__restrict__ u, int last, const float *__restrict__ bns, int C,
+                                                        float *__restrict__ scale, float *__restrict__ scale_h3, float h3_factor)
+{
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < H; i += 256) s += (double)wv[i] * (double)wv[i];
+    const double ss = block_sum256(s, red);
+    const float inv = 1.0f / ((float)sqrt(ss) + 1e-12f);
+    for (int i = threadIdx.x; i < H; i += 256) u[i] = wv[i] * inv;
+    if (!last) return;
+    const float sigma = (float)(ss * (double)inv);                       // u . wv = |wv|^2 / (|wv| + eps)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sc = bns[c] / sigma;                                 // conv(x, w_bar / sigma) = conv(x, w_bar) / sigma
+        scale[c] = sc;
+        scale_h3[c] = sc * h3_factor;
+    }
+}
+
 int ensure_workspace(gl_dcgan *g, int64_t n)
 {
     int64_t want = g->chunk > 0 ? g->chunk : 4096;
@@ -254,6 +325,9 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->h3_dirty = true;
     for (int l = 0; l < 5; ++l) { g->wsplit[l] = nullptr; g->wexp[l] = 0; g->scale_h3[l] = g->shift_h3[l] = nullptr; }
     g->have_att = false;
+    g->sn_iters = 1;
+    g->sn_hold = false;
+    for (int l = 0; l < 4; ++l) { g->have_sn[l] = false; g->sn_w[l] = g->sn_u[l] = g->sn_v[l] = g->sn_wv[l] = g->sn_bns[l] = nullptr; }
     g->att_w = g->att_wsplit = g->att_bias = g->att_ones = g->att_scale_h3 = nullptr;
     g->att_gamma = 0.0f;
     g->att_cols = g->att_cols_pad = g->att_wexp = 0;
@@ -284,6 +358,7 @@ int gl_dcgan_destroy(gl_dcgan *g)
     (void)hipFree(g->ws_qkv);
     (void)hipFree(g->ident_scale);
     (void)hipFree(g->ident_shift);
+    for (int l = 0; l < 4; ++l) { (void)hipFree(g->sn_w[l]); (void)hipFree(g->sn_u[l]); (void)hipFree(g->sn_v[l]); (void)hipFree(g->sn_wv[l]); (void)hipFree(g->sn_bns[l]); }
     delete g;
     return GL_OK;
 }
@@ -408,6 +483,46 @@ int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale, const float 
     return GL_OK;
 }
 
+/* Spectral normalisation of layer 0..3 (VAEGAN's SpectralNorm(ConvTranspose2d), gan_models/vaegan/ops.py:23-75, train.py:112-123): w_bar
+ * [C_in][C_out][4][4] (also installs the convolution weights), the power-iteration vectors u [C_in], v [C_out * 16], the folded BatchNorm
+ * scale gamma / sqrt(var + eps) and the folded shift (bias - mean) * scale + beta per output channel.  From then on EVERY gl_dcgan_forward
+ * first runs `power_iterations` steps of v = normalise(W^T u), u = normalise(W v) on the device, sigma = u . W v, and uses scale / sigma in
+ * the layer's epilogue -- the reference does this on every forward, also in eval mode. */
+int gl_dcgan_set_spectral_norm(gl_dcgan *g, int layer, const float *w_bar, const float *u, const float *v, const float *bn_scale, const float *shift,
+                               int power_iterations)
+{
+    GL_REQUIRE(g && w_bar && u && v && bn_scale && shift && layer >= 0 && layer < 4 && power_iterations >= 1, "gl_dcgan_set_spectral_norm: bad argument");
+    int rc = gl_dcgan_set_conv_weight(g, layer, w_bar);
+    if (rc != GL_OK) return rc;
+    const int H = g->cin[layer], C = g->cout[layer], Wd = C * 16;
+    rc = upload(g->ctx, &g->sn_w[layer], std::vector<float>(w_bar, w_bar + (size_t)H * Wd));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->sn_u[layer], std::vector<float>(u, u + H));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->sn_v[layer], std::vector<float>(v, v + Wd));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->sn_wv[layer], std::vector<float>(H, 0.0f));
+    if (rc == GL_OK) rc = upload(g->ctx, &g->sn_bns[layer], std::vector<float>(bn_scale, bn_scale + C));
+    if (rc == GL_OK) rc = gl_dcgan_set_affine(g, layer, bn_scale, shift);       // shift is final; scale is rewritten by every forward
+    if (rc != GL_OK) return rc;
+    g->sn_iters = power_iterations;
+    g->have_sn[layer] = true;
+    return GL_OK;
+}
+
+int gl_dcgan_set_spectral_hold(gl_dcgan *g, int hold)
+{
+    GL_REQUIRE(g, "gl_dcgan_set_spectral_hold: NULL generator");
+    g->sn_hold = hold != 0;
+    return GL_OK;
+}
+
+int gl_dcgan_get_spectral_state(gl_dcgan *g, int layer, float *u_host, float *v_host)
+{
+    GL_REQUIRE(g && layer >= 0 && layer < 4 && g->have_sn[layer] && u_host && v_host, "gl_dcgan_get_spectral_state: bad argument / layer has no spectral norm");
+    GL_HIP(hipMemcpyAsync(u_host, g->sn_u[layer], (size_t)g->cin[layer] * 4, hipMemcpyDeviceToHost, g->ctx->stream));
+    GL_HIP(hipMemcpyAsync(v_host, g->sn_v[layer], (size_t)g->cout[layer] * 16 * 4, hipMemcpyDeviceToHost, g->ctx->stream));
+    GL_HIP(hipStreamSynchronize(g->ctx->stream));
+    return GL_OK;
+}
+
 /* SelfAttention(in_dim = C2) on the output of layer 2 (16 x 16 x C2, C2 = features_g * 4): query/key conv weights [C2/8][C2],
  * value conv weight [C2][C2] (1x1 convs), biases, gamma.  gan_models/vaegan/ops.py:86-120. */
 int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const float *wk, const float *bk, const float *wv, const float *bv, float gamma)
@@ -493,6 +608,22 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
     if (h3) {
         rc = dcgan_prepare_h3(g);
         if (rc != GL_OK) return rc;
+    }
+    for (int l = 0; l < 4; ++l) {
+        if (!g->have_sn[l] || g->sn_hold) continue;
+        if (!g->scale_h3[l]) {                                      // fp32 mode never built the split-path copies
+            rc = dcgan_prepare_h3(g);
+            if (rc != GL_OK) return rc;
+        }
+        const int H = g->cin[l], C = g->cout[l], Wd = C * 16;
+        for (int it = 0; it < g->sn_iters; ++it) {
+            hipLaunchKernelGGL(sn_wt_u_kernel, dim3((unsigned)gl_ceil_div(Wd, 256)), dim3(256), 0, ctx->stream, g->sn_w[l], g->sn_u[l], H, Wd, g->sn_v[l]);
+            hipLaunchKernelGGL(sn_normalize_kernel, dim3(1), dim3(256), 0, ctx->stream, g->sn_v[l], Wd);
+            hipLaunchKernelGGL(sn_w_v_kernel, dim3((unsigned)H), dim3(256), 0, ctx->stream, g->sn_w[l], g->sn_v[l], Wd, g->sn_wv[l]);
+            hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, g->sn_wv[l], H, g->sn_u[l], it + 1 == g->sn_iters ? 1 : 0, g->sn_bns[l], C,
+                               g->scale[l], g->scale_h3[l], std::ldexp(1.0f, -g->wexp[l]));
+        }
+        GL_LAUNCH_CHECK();
     }
     auto launch = [&](GlGatherConv &p, int layer, int phases) {
         if (!h3) return gl_launch_gather_conv(ctx, p, phases);

@@ -28,10 +28,6 @@ def _np(v):
     return np.ascontiguousarray(v, dtype=np.float32)
 
 
-def _l2normalize(v, eps=1e-12):
-    return (v / (np.float32(np.linalg.norm(v)) + np.float32(eps))).astype(np.float32)
-
-
 class Generator:
     def __init__(self, z_dim, d=64, ctx=None):
         self.z_dim, self.d = int(z_dim), int(d)
@@ -68,16 +64,19 @@ class Generator:
     def load_state_dict(self, sd, strict=True):
         h = self._ensure()
         lib = self.ctx.lib
-        self._sn = []
         for l in range(4):
             name = "deconv%d" % (l + 1)
             w = _np(sd[name + ".module.weight_bar"])
             if w.shape != (self.chans[l], self.chans[l + 1], 4, 4):
                 raise ValueError("%s.module.weight_bar has shape %s" % (name, w.shape))
-            check(lib.gl_dcgan_set_conv_weight(h, l, w.ctypes.data_as(_p)))
-            self._sn.append({"w": w.reshape(w.shape[0], -1), "u": _np(sd[name + ".module.weight_u"]).copy(), "v": _np(sd[name + ".module.weight_v"]).copy(),
-                             "bias": _np(sd[name + ".module.bias"]),
-                             "bn": [_np(sd["%s_bn.%s" % (name, k)]) for k in ("weight", "bias", "running_mean", "running_var")]})
+            u, v, bias = (_np(sd[name + ".module." + k]) for k in ("weight_u", "weight_v", "bias"))
+            g, b, mu, var = (_np(sd["%s_bn.%s" % (name, k)]) for k in ("weight", "bias", "running_mean", "running_var"))
+            # BatchNorm(eval) and the ConvTranspose bias fold into y = conv(x, w_bar) * (bn_s / sigma) + shift; sigma is advanced on the device
+            bn_s = g.astype(np.float64) / np.sqrt(var.astype(np.float64) + 1e-5)
+            shift = ((bias.astype(np.float64) - mu) * bn_s + b).astype(np.float32)
+            bn_s = bn_s.astype(np.float32)
+            check(lib.gl_dcgan_set_spectral_norm(h, l, w.ctypes.data_as(_p), u.ctypes.data_as(_p), v.ctypes.data_as(_p), bn_s.ctypes.data_as(_p),
+                                                 shift.ctypes.data_as(_p), int(self.power_iterations)))
         w5, b5 = _np(sd["deconv5.weight"]), _np(sd["deconv5.bias"])
         check(lib.gl_dcgan_set_conv_weight(h, 4, w5.ctypes.data_as(_p)))
         check(lib.gl_dcgan_set_out_bias(h, b5.ctypes.data_as(_p)))
@@ -92,29 +91,15 @@ class Generator:
         return "<All keys matched successfully>"
 
     def state_dict(self):
-        """the spectral-norm state after the forwards run so far"""
+        """the spectral-norm state after the forwards run so far (it lives on the device)"""
         out = {}
-        for l, s in enumerate(self._sn):
-            out["deconv%d.module.weight_u" % (l + 1)] = s["u"].copy()
-            out["deconv%d.module.weight_v" % (l + 1)] = s["v"].copy()
+        for l in range(4):
+            u = np.empty(self.chans[l], np.float32)
+            v = np.empty(self.chans[l + 1] * 16, np.float32)
+            check(self.ctx.lib.gl_dcgan_get_spectral_state(self._handle, l, u.ctypes.data_as(_p), v.ctypes.data_as(_p)))
+            out["deconv%d.module.weight_u" % (l + 1)] = u
+            out["deconv%d.module.weight_v" % (l + 1)] = v
         return out
-
-    def _advance_spectral_norm(self):
-        """SpectralNorm._update_u_v (ops.py:32-44), fp32 on the host, then the folded epilogue per layer"""
-        lib, h = self.ctx.lib, self._handle
-        for l, s in enumerate(self._sn):
-            w = s["w"]                                  # [height = C_in, C_out * 16]
-            # einsum, not `@`: these matvecs are tiny, and a threaded BLAS call here leaves spinning worker threads that
-            # delay the HIP runtime's completion handling of the kernels launched next (measured: +70 ms per forward)
-            for _ in range(self.power_iterations):
-                s["v"] = _l2normalize(np.einsum("ij,i->j", w, s["u"]))
-                s["u"] = _l2normalize(np.einsum("ij,j->i", w, s["v"]))
-            sigma = np.float32(np.einsum("i,i->", s["u"], np.einsum("ij,j->i", w, s["v"])))
-            g, b, mu, var = s["bn"]
-            bn_s = g.astype(np.float64) / np.sqrt(var.astype(np.float64) + 1e-5)
-            scale = (bn_s / float(sigma)).astype(np.float32)             # conv(x, w_bar / sigma) = conv(x, w_bar) / sigma
-            shift = ((s["bias"].astype(np.float64) - mu) * bn_s + b).astype(np.float32)
-            check(lib.gl_dcgan_set_affine(h, l, scale.ctypes.data_as(_p), shift.ctypes.data_as(_p)))
 
     def eval(self):
         return self
@@ -140,7 +125,7 @@ class Generator:
         n = z.shape[0]
         if int(np.prod(z.shape[1:], dtype=np.int64)) != self.z_dim:
             raise ValueError("expected z of shape [N,%d,1,1], got %s" % (self.z_dim, z.shape))
-        self._advance_spectral_norm()                   # one power iteration per forward, as in the reference
+        # gl_dcgan_forward advances the spectral-norm state by one power iteration per call on the device, as the reference does
         shape = (n, 3, 64, 64)
         f32 = self.ctx.empty(shape, np.float32) if want_f32 else None
         u8 = self.ctx.empty(shape, np.uint8) if want_u8 else None
@@ -150,7 +135,11 @@ class Generator:
             import warnings
             warnings.warn("split-fp16 generator path saturated for these weights; falling back to fp32 MFMA products")
             self.set_precision(0)
-            check(self.ctx.lib.gl_dcgan_forward(self._handle, _p(z.ptr), n, _p(f32.ptr if f32 else 0), _p(u8.ptr if u8 else 0)))
+            check(self.ctx.lib.gl_dcgan_set_spectral_hold(self._handle, 1))
+            try:
+                check(self.ctx.lib.gl_dcgan_forward(self._handle, _p(z.ptr), n, _p(f32.ptr if f32 else 0), _p(u8.ptr if u8 else 0)))
+            finally:
+                check(self.ctx.lib.gl_dcgan_set_spectral_hold(self._handle, 0))
         return f32, u8
 
     def forward(self, input):

@@ -172,6 +172,15 @@ int gl_dcgan_set_precision(gl_dcgan *g, int mode);
  * the epilogue of layers 0..3 set directly (the caller folds 1/sigma of SpectralNorm, the ConvTranspose bias and
  * BatchNorm into scale/shift), and SelfAttention (gan_models/vaegan/ops.py:86-120) on the 16 x 16 output of layer 2. */
 int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale_host, const float *shift_host);
+/* SpectralNorm(ConvTranspose2d) of layer 0..3 (gan_models/vaegan/ops.py:23-75): w_bar [C_in][C_out][4][4] (also installs the layer's weights), power-iteration
+ * vectors u [C_in] and v [C_out * 16], bn_scale = gamma / sqrt(var + eps) and shift = (conv bias - mean) * bn_scale + beta per output channel.  Every
+ * gl_dcgan_forward then advances u, v by `power_iterations` steps ON THE DEVICE and divides the layer's epilogue scale by sigma = u . W v, as the reference does
+ * on every forward (also in eval mode).  gl_dcgan_get_spectral_state copies the current u, v back (state_dict). */
+int gl_dcgan_set_spectral_norm(gl_dcgan *g, int layer, const float *w_bar_host, const float *u_host, const float *v_host, const float *bn_scale_host,
+                               const float *shift_host, int power_iterations);
+int gl_dcgan_get_spectral_state(gl_dcgan *g, int layer, float *u_host, float *v_host);
+/* hold != 0: forwards reuse the current u, v, sigma (re-running the SAME call, e.g. in the other arithmetic mode) */
+int gl_dcgan_set_spectral_hold(gl_dcgan *g, int hold);
 int gl_dcgan_set_attention(gl_dcgan *g, const float *wq_host, const float *bq_host, const float *wk_host, const float *bk_host, const float *wv_host,
                            const float *bv_host, float gamma);
 
