@@ -1,6 +1,7 @@
 // Internal definitions shared by the HIP translation units of libganleaks_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -61,6 +62,20 @@ void gl_set_error(const char *fmt, ...);
     } while (0)
 
 static inline int64_t gl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// run `body` once per device ordinal (function attributes such as the dynamic-LDS limit are per device, and a process may hold
+// contexts on several GPUs); `body` may use GL_HIP (returns on error; the lock is released by the guard)
+#define GL_ONCE_PER_DEVICE(ctx, body)                                                        \
+    do {                                                                                     \
+        static std::mutex _mu;                                                               \
+        static unsigned _mask = 0;                                                           \
+        std::lock_guard<std::mutex> _lk(_mu);                                                \
+        const unsigned _bit = 1u << ((ctx)->device & 31);                                    \
+        if (!(_mask & _bit)) {                                                               \
+            body;                                                                            \
+            _mask |= _bit;                                                                   \
+        }                                                                                    \
+    } while (0)
 
 // exact-integer L2 path: S = sum_k (u_q - u_n)^2 <= 65025 d, packed as key = S << shift | global index.  The key stays below 2^63
 // because the cross-GPU minimum runs on the int64 view of the keys; shift is 32 for d <= 33025 (everything up to 3 x 104 x 104)

@@ -347,13 +347,10 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
     const int n_tiles = p.cols_pad / BN;
     GL_REQUIRE(p.cols_pad % BN == 0 && p.cols <= p.cols_pad, "gather_conv: cols_pad=%d must be a multiple of %d", p.cols_pad, BN);
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv: grid too large");
-    static bool attr_set = false;
     const int lds_req = lds;
     auto kern = gather_conv_kernel<WAVES_M, WAVES_N, TM, TN>;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_req));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_req)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(THREADS), lds_req, ctx->stream, p, (int)m_tiles, n_tiles, phases);
     GL_LAUNCH_CHECK();

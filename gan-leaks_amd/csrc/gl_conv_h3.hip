@@ -256,13 +256,10 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
     const int64_t m_tiles = gl_ceil_div(p.positions, HTP);
     const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
-    static bool attr_set = false;
     constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
     auto kern = gather_conv_h3_kernel<WC, WP, TC, TP>;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
     hipLaunchKernelGGL(kern, dim3((unsigned)(m_tiles * n_tiles * phases)), dim3(64 * WC * WP), lds, ctx->stream, p, (int)m_tiles, n_tiles, phases);
     GL_LAUNCH_CHECK();

@@ -186,12 +186,9 @@ template <int C>
 int launch_attention_core(gl_ctx *ctx, bool split, const float *qkv, const float *x, float *y, int64_t images, float gamma)
 {
     constexpr int lds = (256 * C + (C / 8) * 256) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_core_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_core_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_core_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_core_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     if (split)
         hipLaunchKernelGGL((attention_core_kernel<C, true>), dim3((unsigned)images), dim3(512), lds, ctx->stream, qkv, reinterpret_cast<const char *>(x),
                            reinterpret_cast<char *>(y), gamma, ctx->h3_sat);

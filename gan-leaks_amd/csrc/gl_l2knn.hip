@@ -285,23 +285,17 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
     const int64_t stride = gl_l2_row_stride(d);
     const int64_t q_tiles = gl_ceil_div(nq, TILE_Q), n_tiles = gl_ceil_div(n_rows, TILE_N);
     GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_l2_knn_i8: grid too large");
-    static bool attr_set = false;
     const int lds = 4 * OPER_BYTES;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_L2_KNN);
     // the large tile needs enough tiles to fill 256 CUs; GL_L2_TILE=128|256 forces one (tuning / tests)
     static const int force_tile = getenv("GL_L2_TILE") ? atoi(getenv("GL_L2_TILE")) : 0;
     const int64_t q256 = gl_ceil_div(nq, BT), n256 = gl_ceil_div(n_rows, BT);
     if (d <= 66051 && force_tile != 128 && (force_tile == 256 || q256 * n256 >= 1024)) {
-        static bool attr256 = false;
-        if (!attr256) {
-            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BOPER));
-            attr256 = true;
-        }
+        GL_ONCE_PER_DEVICE(ctx, \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BOPER)););
         hipLaunchKernelGGL(l2_knn_i8_256_kernel, dim3((unsigned)(q256 * n256)), dim3(512), 4 * BOPER, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows, index_base,
                            query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q256, (int)n256, shift);
         GL_LAUNCH_CHECK();

@@ -1038,12 +1038,9 @@ int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm
     GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V16_dev) | reinterpret_cast<uintptr_t>(query_V16_dev)) & 15) == 0, "gl_feat_knn_h1: rows must be 16-byte aligned");
     const int64_t q_tiles = gl_ceil_div(nq, GT), n_tiles = gl_ceil_div(n_rows, GT);
     GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn_h1: grid too large");
-    static bool attr_set = false;
     const int lds = 4 * GOPER;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
     hipLaunchKernelGGL(feat_knn_h1_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev), bank_norm_dev, n_rows,
                        index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
@@ -1062,12 +1059,9 @@ int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev
     GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V_dev) | reinterpret_cast<uintptr_t>(query_V_dev)) & 15) == 0, "gl_feat_knn: rows must be 16-byte aligned");
     const int64_t q_tiles = gl_ceil_div(nq, FT), n_tiles = gl_ceil_div(n_rows, FT);
     GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn: grid too large");
-    static bool attr_set = false;
     const int lds = 4 * FOPER;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
     hipLaunchKernelGGL(feat_knn_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, reinterpret_cast<const char *>(bank_V_dev), bank_norm_dev, n_rows,
                        index_base, reinterpret_cast<const char *>(query_V_dev), query_norm_dev, nq, K, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles,
@@ -1100,12 +1094,9 @@ int gl_rows_knn_split(gl_ctx *ctx, const void *bank_V_dev, const float *bank_nor
     GL_REQUIRE(((reinterpret_cast<uintptr_t>(bank_V_dev) | reinterpret_cast<uintptr_t>(query_V_dev)) & 15) == 0, "gl_rows_knn_split: rows must be 16-byte aligned");
     const int64_t q_tiles = gl_ceil_div(nq, FT), n_tiles = gl_ceil_div(n_rows, FT);
     GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_rows_knn_split: grid too large");
-    static bool attr_set = false;
     const int lds = 4 * FOPER;
-    if (!attr_set) {
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
     hipLaunchKernelGGL(feat_knn_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(256), lds, ctx->stream, reinterpret_cast<const char *>(bank_V_dev), bank_norm_dev, n_rows,
                        index_base, reinterpret_cast<const char *>(query_V_dev), query_norm_dev, nq, gl_rows_split_dim(d), reinterpret_cast<unsigned long long *>(keys_dev),
