@@ -62,6 +62,23 @@ def plot_roc(pos_results, neg_results):
     return fpr, tpr, threshold, auc, ap, precision
 
 
+def plot_hist(pos_dist, neg_dist, save_file):
+    """eval_roc.py:28-37: normalised histograms (100 bins) of the positive and negative distances"""
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    pos_dist, neg_dist = np.asarray(pos_dist).reshape(-1), np.asarray(neg_dist).reshape(-1)
+    plt.figure()
+    for d, label in ((pos_dist, 'positive'), (neg_dist, 'negative')):
+        plt.hist(d, bins=100, alpha=0.5, weights=np.full(d.shape, 1.0 / d.size), label=label)
+    plt.legend(loc='upper right')
+    plt.tight_layout()
+    plt.xlabel('distance')
+    plt.ylabel('normalized frequency')
+    plt.savefig(save_file)
+    plt.close()
+
+
 def parse_arguments(argv=None):
     """eval_roc.py:43-54 (same flags)"""
     parser = argparse.ArgumentParser()

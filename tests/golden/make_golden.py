@@ -313,7 +313,58 @@ def make_png(ref_utils):
     print("png_case order:", [os.path.relpath(q, d) for q in paths])
 
 
+def zsplit_case(root):
+    """a miniature CelebA: identity groups of 4, 4, 4 (private at num_same_id = 4), 3, 2, 3, 3 (public) and 5 (neither) pictures of
+    218 x 178 random pixels, annotation lines `<identity> <file>`.  Shared by this script and tests/test_zsplit.py."""
+    import types
+    import PIL.Image
+    rng = np.random.default_rng(2718)
+    sizes = [("idA", 4), ("idD", 3), ("idB", 4), ("idH", 5), ("idE", 2), ("idC", 4), ("idF", 3), ("idG", 3)]
+    src = os.path.join(root, "img_align_celeba")
+    os.makedirs(src, exist_ok=True)
+    lines, k = [], 0
+    for ident, n in sizes:
+        for _ in range(n):
+            k += 1
+            name = "%06d.jpg.png" % k            # lossless stand-in for CelebA's .jpg; the stem is what the outputs are named after
+            PIL.Image.fromarray(rng.integers(0, 256, size=(218, 178, 3), dtype=np.uint8)).save(os.path.join(src, name))
+            lines.append("%s %s" % (ident, name))
+    ann = os.path.join(root, "identities_ann.txt")
+    with open(ann, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return types.SimpleNamespace(num_images=30, identity_annotations=ann, input_dir=src, output_dir0=os.path.join(root, "train"),
+                                 output_dir1=os.path.join(root, "pos"), output_dir2=os.path.join(root, "neg"), img_size=64, local_config=None,
+                                 num_same_id=4)
+
+
+def dir_digest(d):
+    """sorted file names + CRC32 of the decoded pixels of each file"""
+    import zlib
+    import PIL.Image
+    names = sorted(os.listdir(d))
+    return names, [zlib.crc32(np.asarray(PIL.Image.open(os.path.join(d, n))).tobytes()) for n in names]
+
+
+def make_zsplit():
+    import tempfile
+    zs = _refimport.load("z_split.py", "ref_z_split")
+    with tempfile.TemporaryDirectory() as root:
+        args = zsplit_case(root)
+        np.random.seed(123)                      # the reference draws its random crops from numpy's global state
+        zs.main(args)
+        out = {}
+        for key, d in (("train", args.output_dir0), ("pos", args.output_dir1), ("neg", args.output_dir2)):
+            names, crcs = dir_digest(d)
+            out[key + "_names"] = np.array(names)
+            out[key + "_crc"] = np.array(crcs, np.uint32)
+        np.savez(os.path.join(HERE, "zsplit_case.npz"), **out)
+        print("zsplit: %d train, %d pos, %d neg files" % (len(out["train_names"]), len(out["pos_names"]), len(out["neg_names"])))
+
+
 if __name__ == "__main__":
+    if "--zsplit-only" in sys.argv:
+        make_zsplit()
+        sys.exit(0)
     if "--vaegan-only" in sys.argv:      # own process: its `utils` module name collides with attack_models/utils.py
         make_vaegan()
         sys.exit(0)
@@ -340,5 +391,6 @@ if __name__ == "__main__":
     make_dcgan(dc, wg)
     make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
     make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
+    make_zsplit()
     import subprocess
     subprocess.run([sys.executable, os.path.abspath(__file__), "--vaegan-only"], check=True)

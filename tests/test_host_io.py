@@ -74,6 +74,15 @@ def test_eval_roc_main_files(gl, golden_dir, tmp_path):
     eval_roc.main(args)
 
 
+def test_plot_hist_writes_a_figure(gl, tmp_path):
+    pytest.importorskip("matplotlib")
+    from ganleaks_amd.attack_models.eval_roc import plot_hist
+    rng = np.random.default_rng(0)
+    out = tmp_path / "hist.png"
+    plot_hist(rng.normal(0.05, 0.01, (200, 1)), rng.normal(0.08, 0.01, (180, 1)), str(out))
+    assert out.stat().st_size > 1000
+
+
 def test_fbb_cli_surface(gl):
     from ganleaks_amd.attack_models import fbb
     a = fbb.parse_arguments([])
