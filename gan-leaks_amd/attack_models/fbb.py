@@ -17,7 +17,7 @@ import warnings
 
 import numpy as np
 
-from ..attack import Bank, attack  # noqa: F401  (re-export)
+from ..attack import Bank, _budget_bytes, attack  # noqa: F401  (re-export)
 from .utils import (Loss, check_folder, get_filepaths_from_dir, read_images_u8_nchw, save_files)
 
 
@@ -140,6 +140,7 @@ def main(args):
         subdirs = [args.syn_data_path]
     distance = getattr(args, "distance", "l2-lpips")
     results = []
+    queries = None
     for subdir in subdirs:
         args.syn_data_path = subdir
         args.params = subdir.split('/')[-1] if args.hyperparameter_search else args.params
@@ -150,10 +151,23 @@ def main(args):
         resolution = args.resolution
 
         syn_imgs = read_images_u8_nchw(get_filepaths_from_dir(subdir, ext='png'), resolution)
-        pos_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.pos_data_dir, ext='png'), resolution)
-        neg_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.neg_data_dir, ext='png'), resolution)
-
-        custom_loss = Loss(distance, if_norm_reg=False)          # fbb.py:148 (loads the LPIPS model for 'l2-lpips')
+        if queries is None or queries[0] != (args.pos_data_dir, args.neg_data_dir, resolution, distance):
+            # the query sets do not change across the banks of a hyper-parameter sweep (fbb.py:114-123 re-reads them for every
+            # sub-directory): read and prepare them once -- int8 rows, or VGG16/LPIPS search rows -- and reuse them for every bank
+            pos_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.pos_data_dir, ext='png'), resolution)
+            neg_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.neg_data_dir, ext='png'), resolution)
+            custom_loss = Loss(distance, if_norm_reg=False)      # fbb.py:148 (loads the LPIPS model for 'l2-lpips')
+            both = np.concatenate([pos_query_imgs, neg_query_imgs])
+            if distance == "l2-lpips":
+                model = custom_loss.lpips_model
+                row = 2 * int(model.ctx.lib.gl_lpips_search_dim(resolution, resolution)) if model.search_rows == "fp16" else 4 * int(
+                    model.ctx.lib.gl_lpips_feature_dim(resolution, resolution))
+                # only when the rows fit the streaming budget; otherwise attack() slices the raw queries itself
+                prepared = model.features(both, role=model.search_role("query")) if len(both) * row <= _budget_bytes() else both
+            else:
+                prepared = Bank.from_images(both, keep_u8=True) if len(both) else both
+            queries = ((args.pos_data_dir, args.neg_data_dir, resolution, distance), pos_query_imgs, neg_query_imgs, custom_loss, prepared)
+        _, pos_query_imgs, neg_query_imgs, custom_loss, prepared = queries
         n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
         if n_rows == 0:
             raise ValueError("torch.cat(): expected a non-empty list of Tensors")
@@ -161,8 +175,7 @@ def main(args):
         # prepared rows -- int8 rows or VGG16/LPIPS feature rows -- are built once, and streamed through HBM in chunks when
         # they would not fit (ganleaks_amd.attack, $GANLEAKS_CHUNK_GB)
         n_pos = len(pos_query_imgs)
-        all_d, all_i = attack(np.concatenate([pos_query_imgs, neg_query_imgs]), syn_imgs, distance=distance, batch_size=args.BATCH_SIZE,
-                              lpips=custom_loss.lpips_model)
+        all_d, all_i = attack(prepared, syn_imgs, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
         pos_d, pos_i, neg_d, neg_i = all_d[:n_pos], all_i[:n_pos], all_d[n_pos:], all_i[n_pos:]
         pos_loss = pos_d.astype(np.float64).reshape(-1, 1)          # python floats -> float64 [Q,1] (fbb.py:160)
         plt_pos_idx = pos_i.reshape(-1, 1)
