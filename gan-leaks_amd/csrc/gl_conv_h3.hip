@@ -34,7 +34,7 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 // tile with 8 waves of 64 x 64, 256 x 256 with 4 waves of 128 x 128 (1 wave per SIMD), 128 x 512 / 128 x 256 tiles for 128-column
 // layers, a ring of three slices with counted
 // s_waitcnt vmcnt(N), 4 workgroups per CU.
-template <int WC, int WP, int TC = 4, int TP = 4>
+template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
 #if __HIP_DEVICE_COMPILE__
@@ -190,6 +190,76 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
     const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
     const float neg_slope = p.act == 2 ? 0.2f : 1.0f;
     bool saturated = false;
+    if constexpr (FUSE_TAIL) {
+        // The next layer's GEMM (48 columns over this layer's 128 channels) on the activations while they are still in registers.
+        // A wave holds 64 of the 128 channels (tiles i = 0..3) of its 64 positions: a lane's 4 + 4 values of tiles 2s and 2s + 1 form the
+        // 8 k-values of its k group in k-step s (the weights are stored in that order), so the B operands need no data movement.
+        static_assert(WC == 2 && WP == 2 && TC == 4 && TP == 4, "fused tail: 128 x 128 tile");
+        v8h b_hi[2][TP], b_lo[2][TP];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int ch = wc * 64 + i * 16 + 4 * fk;
+            float sc[4], sh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = p.scale[ch + r]; sh[r] = p.shift[ch + r]; }
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = fmaf(acc[i][j][r], sc[r], sh[r]);
+                    t = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
+                    const float c = fminf(fmaxf(t, -65504.0f), 65504.0f);
+                    saturated |= (c != t) && (o4[j] >= 0);
+                    const _Float16 h = (_Float16)c;
+                    b_hi[i >> 1][j][(i & 1) * 4 + r] = h;
+                    b_lo[i >> 1][j][(i & 1) * 4 + r] = (_Float16)(c - (float)h);
+                }
+        }
+        v4f pacc[3][TP];
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pacc[pt][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        const v8h *tw = reinterpret_cast<const v8h *>(p.tail_w) + (size_t)wc * 3 * 2 * 2 * 64;
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const v8h a_hi = tw[((pt * 2 + s2) * 2 + 0) * 64 + frow * 4 + fk];
+                const v8h a_lo = tw[((pt * 2 + s2) * 2 + 1) * 64 + frow * 4 + fk];
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    pacc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, b_hi[s2][j], pacc[pt][j], 0, 0, 0);
+                    pacc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_lo[s2][j], pacc[pt][j], 0, 0, 0);
+                    pacc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi[s2][j], pacc[pt][j], 0, 0, 0);
+                }
+            }
+        // the two channel halves (waves wc = 0, 1 of the same positions) are summed through LDS, then the wc = 0 wave stores
+        float *xch = reinterpret_cast<float *>(smem + 4096) + (size_t)wp_ * 3 * TP * 4 * 64;
+        if (wc == 1) {
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xch[((pt * TP + j) * 4 + r) * 64 + lane] = pacc[pt][j][r];
+        }
+        __syncthreads();
+        if (wc == 0) {
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    const int o = o4[j];
+                    if (o < 0) continue;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = pacc[pt][j][r] + xch[((pt * TP + j) * 4 + r) * 64 + lane];
+                        p.tail_out[(int64_t)(pt * 16 + 4 * fk + r) * p.tail_ld + o] = v * p.tail_scale;
+                    }
+                }
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;     // first of this lane's 4 consecutive channels
@@ -228,6 +298,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
             }
         }
     }
+    }
     if (__any(saturated) && lane == 0) atomicAdd(p.sat_flag, 1);
 #endif
 }
@@ -249,7 +320,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 
 }  // namespace
 
-template <int WC, int WP, int TC = 4, int TP = 4>
+template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false>
 static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
     constexpr int HTC = 16 * TC * WC, HTP = 16 * TP * WP;
@@ -257,7 +328,7 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
     const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
     constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
-    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP>;
+    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP, FUSE_TAIL>;
     GL_ONCE_PER_DEVICE(ctx, \
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
@@ -287,6 +358,10 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     if (p.positions == 0) return GL_OK;
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
     // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
+    if (p.tail_w) {
+        GL_REQUIRE(p.cols == 128 && p.cols_pad == 128 && p.cmod == 128 && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 128-channel layer");
+        return launch_h3<2, 2, 4, 4, true>(ctx, p, phases);
+    }
     if (p.cols <= 64) return launch_h3<1, 4>(ctx, p, phases);
     // wide layers with enough work to fill the chip: 256 channels x 256 positions, 8 waves of 128 x 64 (24 LDS fragment reads per 96
     // MFMAs instead of 16 per 48, half the staging per MFMA): +7 % on the DCGAN stack (A/B on one device, profiles/r01/README.md)
@@ -318,4 +393,24 @@ void gl_split_weights_host(const float *w, size_t rows, size_t K, float scale, v
             *reinterpret_cast<_Float16 *>(dst) = hi;
             *reinterpret_cast<_Float16 *>(dst + 64) = lo;
         }
+}
+
+void gl_pack_tail_weights_host(const float *w, float scale, void *out)
+{
+    _Float16 *o = reinterpret_cast<_Float16 *>(out);
+    for (int half = 0; half < 2; ++half)
+        for (int pt = 0; pt < 3; ++pt)
+            for (int st = 0; st < 2; ++st)
+                for (int row = 0; row < 16; ++row)
+                    for (int g = 0; g < 4; ++g)
+                        for (int e = 0; e < 8; ++e) {
+                            const int ch = half * 64 + (2 * st + e / 4) * 16 + 4 * g + e % 4;
+                            float v = w[(size_t)(pt * 16 + row) * 128 + ch] * scale;
+                            v = v > 65504.0f ? 65504.0f : (v < -65504.0f ? -65504.0f : v);
+                            const _Float16 hi = (_Float16)v;
+                            const _Float16 lo = (_Float16)(v - (float)hi);
+                            const size_t base = ((((size_t)half * 3 + pt) * 2 + st) * 2) * 512 + (size_t)(row * 4 + g) * 8 + e;
+                            o[base] = hi;
+                            o[base + 512] = lo;
+                        }
 }

@@ -6,6 +6,7 @@
 // Activations are NHWC fp32 and stay resident in HBM for a whole pass of `chunk` images.
 #include "gl_conv.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 struct gl_dcgan {
@@ -35,6 +36,7 @@ struct gl_dcgan {
     bool sn_hold;              // next forward(s) reuse the current sigma (a re-run of the same call)
     int precision;             // 0 = fp32 MFMA (exact fp32 products), 1 = split-fp16 (three fp16 MFMAs per product, ~22-bit operands)
     float *wsplit[5];
+    void *tail_w;              // layer 4 packed for the epilogue of layer 3 (gl_pack_tail_weights_host), when layer 3 has 128 channels
     int wexp[5];
     std::vector<float> h_scale[4], h_shift[4];
     float *scale_h3[5], *shift_h3[5];
@@ -320,6 +322,7 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->ws_p = nullptr;
     g->precision = 1;
     g->h3_dirty = true;
+    g->tail_w = nullptr;
     for (int l = 0; l < 5; ++l) { g->wsplit[l] = nullptr; g->wexp[l] = 0; g->scale_h3[l] = g->shift_h3[l] = nullptr; }
     g->have_att = false;
     g->sn_iters = 1;
@@ -355,6 +358,7 @@ int gl_dcgan_destroy(gl_dcgan *g)
     (void)hipFree(g->ws_qkv);
     (void)hipFree(g->ident_scale);
     (void)hipFree(g->ident_shift);
+    (void)hipFree(g->tail_w);
     for (int l = 0; l < 4; ++l) { (void)hipFree(g->sn_w[l]); (void)hipFree(g->sn_u[l]); (void)hipFree(g->sn_v[l]); (void)hipFree(g->sn_wv[l]); (void)hipFree(g->sn_bns[l]); }
     delete g;
     return GL_OK;
@@ -426,6 +430,13 @@ int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
         gl_split_weights_host(padded.data(), phases * rows128, Kl, std::ldexp(1.0f, e), split.data());
         rc = upload(g->ctx, &g->wsplit[layer], split);
         if (rc != GL_OK) return rc;
+        if (layer == 4 && ci_n == 128 && 16 * co_n == 48) {
+            // the same 48 x 128 weights as the epilogue operand of layer 3 (fused tail, gl_conv.h)
+            std::vector<float> img(24 * 1024 / 4);
+            gl_pack_tail_weights_host(pk.data(), std::ldexp(1.0f, e), img.data());
+            if (!g->tail_w) GL_HIP(hipMalloc(&g->tail_w, 24 * 1024));
+            GL_HIP(hipMemcpy(g->tail_w, img.data(), 24 * 1024, hipMemcpyHostToDevice));
+        }
         g->h3_dirty = true;
     }
     g->have_w[layer] = true;
@@ -602,6 +613,8 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
     if (rc != GL_OK) return rc;
     const int64_t img_elems = (int64_t)g->nc * 64 * 64;
     const bool h3 = g->precision == 1;
+    static const bool no_fuse = getenv("GL_NO_FUSE_TAIL") != nullptr;          // A/B switch
+    const bool fuse_tail = h3 && g->tail_w != nullptr && !no_fuse;
     if (h3) {
         rc = dcgan_prepare_h3(g);
         if (rc != GL_OK) return rc;
@@ -678,6 +691,10 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
                 }
             p.out = g->ws_a[l]; p.Ho = 2 * hw; p.Wo = 2 * hw; p.omul = 2;
             p.scale = g->scale[l]; p.shift = g->shift[l]; p.cmod = g->cout[l]; p.act = 1; p.zero = ctx->zero_page;
+            if (l == 3 && fuse_tail) {
+                // layer 4 (128 -> 3, scatter form) rides in this layer's epilogue: the 32 x 32 x 128 activations are never stored
+                p.tail_w = g->tail_w; p.tail_out = g->ws_p; p.tail_ld = m * 4 * hw * hw; p.tail_scale = std::ldexp(1.0f / kActScale, -g->wexp[4]);
+            }
             rc = launch(p, l, 4);
             if (rc != GL_OK) return rc;
             hw *= 2;
@@ -698,7 +715,7 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
         }
         // layer 4: ConvT k4 s2 p1 -> 3 channels: scatter-form GEMM (48 columns) on the matrix cores,
         // then col2im + bias + tanh (+ quantise)
-        {
+        if (!fuse_tail) {
             GlGatherConv p = {};
             p.in = g->ws_a[3]; p.positions = m * hw * hw; p.H = hw; p.W = hw; p.Cin = g->cin[4];
             p.wpack = g->wpack[4]; p.cols = 16 * g->nc; p.cols_pad = (int)gl_ceil_div(p.cols, 64) * 64; p.ntaps = 1;
