@@ -365,7 +365,7 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     if (p.cols <= 64) return launch_h3<1, 4>(ctx, p, phases);
     // wide layers with enough work to fill the chip: 256 channels x 256 positions, 8 waves of 128 x 64 (24 LDS fragment reads per 96
     // MFMAs instead of 16 per 48, half the staging per MFMA): +7 % on the DCGAN stack (A/B on one device, profiles/r01/README.md)
-    if (p.cols % 256 == 0 && gl_ceil_div(p.positions, 256) * (p.cols / 256) * phases >= 1024) return launch_h3<2, 4, 8, 4>(ctx, p, phases);
+    if (p.cols % 256 == 0 && gl_ceil_div(p.positions, 256) * (p.cols / 256) * phases >= 256) return launch_h3<2, 4, 8, 4>(ctx, p, phases);
     return launch_h3<2, 2>(ctx, p, phases);
 }
 
