@@ -84,6 +84,7 @@ SIGNATURES = {
     "gl_dcgan_set_spectral_norm": (_i, [_p, _i, _p, _p, _p, _p, _p, _i]),
     "gl_dcgan_get_spectral_state": (_i, [_p, _i, _p, _p]),
     "gl_dcgan_set_spectral_hold": (_i, [_p, _i]),
+    "gl_dcgan_set_fuse_tail": (_i, [_p, _i]),
     "gl_dcgan_set_attention": (_i, [_p, _p, _p, _p, _p, _p, _p, ctypes.c_float]),
     "gl_pggan_create": (_i, [_p, _i, _i, _i, _pp]),
     "gl_pggan_destroy": (_i, [_p]),

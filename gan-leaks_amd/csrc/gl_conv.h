@@ -36,7 +36,7 @@ struct GlGatherConv {
     const float *residual;
     const float *zero;          // >= 16 B of zeros (source of out-of-image taps)
     // gather_conv_h3 only, optional: the NEXT layer fused into this one's epilogue when that layer is a per-position GEMM over all of this
-    // layer's 128 output channels with 48 columns (the generator's ConvTranspose2d(128 -> 3, k4 s2 p1) in scatter form): the activations never
+    // layer's 64 or 128 output channels with 48 columns (the generator's ConvTranspose2d(C -> 3, k4 s2 p1) in scatter form): the activations never
     // leave the registers, only tail_out[col * tail_ld + output position] = tail_scale * sum_c act[c] * w[c][col] is written.
     // tail_w: gl_pack_tail_weights_host layout.  `out` is ignored then.
     const void *tail_w;
@@ -45,10 +45,10 @@ struct GlGatherConv {
     float tail_scale;
 };
 
-// host: rows [48][128] of (2^exp-scaled) fp32 tail weights (row = GEMM column, 128 input channels) -> the operand image the fused epilogue
-// reads (24 KiB): [channel half 2][column tile 3][k step 2][hi | lo][row 16][k group 4][8 halves], the 8 halves of k group g holding channels
-// half * 64 + (2 * step + e / 4) * 16 + 4 * g + e % 4  (the order in which a lane of the epilogue holds its activated outputs)
-void gl_pack_tail_weights_host(const float *w48x128, float scale, void *out);
+// host: rows [48][channels] (channels = 64 or 128) of fp32 tail weights (row = GEMM column) -> the operand image the fused epilogue reads
+// (12 KiB per 64 channels): [channel half][column tile 3][k step 2][hi | lo][row 16][k group 4][8 halves], the 8 halves of k group g holding
+// channels half * 64 + (2 * step + e / 4) * 16 + 4 * g + e % 4  (the order in which a lane of the epilogue holds its activated outputs)
+void gl_pack_tail_weights_host(const float *w48xC, int channels, float scale, void *out);
 
 // position of (tap, ci) inside a packed weight row: channel chunks of 32 outermost, taps inside a chunk
 static inline int64_t gl_conv_k_index(int tap, int ci, int ntaps) { return ((int64_t)(ci / 32) * ntaps + tap) * 32 + (ci % 32); }

@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         // The next layer's GEMM (48 columns over this layer's 128 channels) on the activations while they are still in registers.
         // A wave holds 64 of the 128 channels (tiles i = 0..3) of its 64 positions: a lane's 4 + 4 values of tiles 2s and 2s + 1 form the
         // 8 k-values of its k group in k-step s (the weights are stored in that order), so the B operands need no data movement.
-        static_assert(WC == 2 && WP == 2 && TC == 4 && TP == 4, "fused tail: 128 x 128 tile");
+        static_assert((WC == 2 || WC == 1) && TC == 4 && TP == 4, "fused tail: waves of 64 channels x 64 positions, 64 or 128 channels in all");
         v8h b_hi[2][TP], b_lo[2][TP];
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -234,9 +234,9 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                     pacc[pt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, b_hi[s2][j], pacc[pt][j], 0, 0, 0);
                 }
             }
-        // the two channel halves (waves wc = 0, 1 of the same positions) are summed through LDS, then the wc = 0 wave stores
+        // 128 channels: the two channel halves (waves wc = 0, 1 of the same positions) are summed through LDS, then the wc = 0 wave stores
         float *xch = reinterpret_cast<float *>(smem + 4096) + (size_t)wp_ * 3 * TP * 4 * 64;
-        if (wc == 1) {
+        if (WC == 2 && wc == 1) {
 #pragma unroll
             for (int pt = 0; pt < 3; ++pt)
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xch[((pt * TP + j) * 4 + r) * 64 + lane] = pacc[pt][j][r];
         }
-        __syncthreads();
+        if (WC == 2) __syncthreads();
         if (wc == 0) {
 #pragma unroll
             for (int pt = 0; pt < 3; ++pt)
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                     if (o < 0) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float v = pacc[pt][j][r] + xch[((pt * TP + j) * 4 + r) * 64 + lane];
+                        const float v = pacc[pt][j][r] + (WC == 2 ? xch[((pt * TP + j) * 4 + r) * 64 + lane] : 0.0f);
                         p.tail_out[(int64_t)(pt * 16 + 4 * fk + r) * p.tail_ld + o] = v * p.tail_scale;
                     }
                 }
@@ -359,8 +359,8 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
     // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
     if (p.tail_w) {
-        GL_REQUIRE(p.cols == 128 && p.cols_pad == 128 && p.cmod == 128 && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 128-channel layer");
-        return launch_h3<2, 2, 4, 4, true>(ctx, p, phases);
+        GL_REQUIRE((p.cols == 128 || p.cols == 64) && p.cmod == p.cols && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 64- or 128-channel layer");
+        return p.cols == 128 ? launch_h3<2, 2, 4, 4, true>(ctx, p, phases) : launch_h3<1, 4, 4, 4, true>(ctx, p, phases);
     }
     if (p.cols <= 64) return launch_h3<1, 4>(ctx, p, phases);
     // wide layers with enough work to fill the chip: 256 channels x 256 positions, 8 waves of 128 x 64 (24 LDS fragment reads per 96
@@ -395,17 +395,17 @@ void gl_split_weights_host(const float *w, size_t rows, size_t K, float scale, v
         }
 }
 
-void gl_pack_tail_weights_host(const float *w, float scale, void *out)
+void gl_pack_tail_weights_host(const float *w, int channels, float scale, void *out)
 {
     _Float16 *o = reinterpret_cast<_Float16 *>(out);
-    for (int half = 0; half < 2; ++half)
+    for (int half = 0; half < channels / 64; ++half)
         for (int pt = 0; pt < 3; ++pt)
             for (int st = 0; st < 2; ++st)
                 for (int row = 0; row < 16; ++row)
                     for (int g = 0; g < 4; ++g)
                         for (int e = 0; e < 8; ++e) {
                             const int ch = half * 64 + (2 * st + e / 4) * 16 + 4 * g + e % 4;
-                            float v = w[(size_t)(pt * 16 + row) * 128 + ch] * scale;
+                            float v = w[(size_t)(pt * 16 + row) * channels + ch] * scale;
                             v = v > 65504.0f ? 65504.0f : (v < -65504.0f ? -65504.0f : v);
                             const _Float16 hi = (_Float16)v;
                             const _Float16 lo = (_Float16)(v - (float)hi);

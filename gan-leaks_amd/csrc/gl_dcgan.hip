@@ -36,7 +36,8 @@ struct gl_dcgan {
     bool sn_hold;              // next forward(s) reuse the current sigma (a re-run of the same call)
     int precision;             // 0 = fp32 MFMA (exact fp32 products), 1 = split-fp16 (three fp16 MFMAs per product, ~22-bit operands)
     float *wsplit[5];
-    void *tail_w;              // layer 4 packed for the epilogue of layer 3 (gl_pack_tail_weights_host), when layer 3 has 128 channels
+    bool fuse_tail;            // default on (gl_dcgan_set_fuse_tail)
+    void *tail_w;              // layer 4 packed for the epilogue of layer 3 (gl_pack_tail_weights_host), when layer 3 has 64 or 128 channels
     int wexp[5];
     std::vector<float> h_scale[4], h_shift[4];
     float *scale_h3[5], *shift_h3[5];
@@ -323,6 +324,7 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
     g->precision = 1;
     g->h3_dirty = true;
     g->tail_w = nullptr;
+    g->fuse_tail = true;
     for (int l = 0; l < 5; ++l) { g->wsplit[l] = nullptr; g->wexp[l] = 0; g->scale_h3[l] = g->shift_h3[l] = nullptr; }
     g->have_att = false;
     g->sn_iters = 1;
@@ -430,10 +432,10 @@ int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
         gl_split_weights_host(padded.data(), phases * rows128, Kl, std::ldexp(1.0f, e), split.data());
         rc = upload(g->ctx, &g->wsplit[layer], split);
         if (rc != GL_OK) return rc;
-        if (layer == 4 && ci_n == 128 && 16 * co_n == 48) {
-            // the same 48 x 128 weights as the epilogue operand of layer 3 (fused tail, gl_conv.h)
+        if (layer == 4 && (ci_n == 128 || ci_n == 64) && 16 * co_n == 48) {
+            // the same 48 x C weights as the epilogue operand of layer 3 (fused tail, gl_conv.h)
             std::vector<float> img(24 * 1024 / 4);
-            gl_pack_tail_weights_host(pk.data(), std::ldexp(1.0f, e), img.data());
+            gl_pack_tail_weights_host(pk.data(), ci_n, std::ldexp(1.0f, e), img.data());
             if (!g->tail_w) GL_HIP(hipMalloc(&g->tail_w, 24 * 1024));
             GL_HIP(hipMemcpy(g->tail_w, img.data(), 24 * 1024, hipMemcpyHostToDevice));
         }
@@ -571,6 +573,15 @@ int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const 
 
 /* 0 = fp32 MFMA (every product exact in fp32), 1 = split-fp16 (default): operands carried as hi + lo halves (~22 bits), three fp16
  * MFMAs per product, fp32 accumulation.  Both meet the 1e-4 parity bound; 1 is ~2-3x faster. */
+/* on (default): with split-fp16 arithmetic and a last hidden layer of 64 or 128 channels, the 3-channel output layer is evaluated in that layer's
+ * epilogue and its activations are never stored; off: the two layers run as separate launches (same values up to fp32 summation order). */
+int gl_dcgan_set_fuse_tail(gl_dcgan *g, int on)
+{
+    GL_REQUIRE(g, "gl_dcgan_set_fuse_tail: NULL generator");
+    g->fuse_tail = on != 0;
+    return GL_OK;
+}
+
 int gl_dcgan_set_precision(gl_dcgan *g, int mode)
 {
     GL_REQUIRE(g && (mode == 0 || mode == 1), "gl_dcgan_set_precision: mode must be 0 or 1");
@@ -613,8 +624,7 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
     if (rc != GL_OK) return rc;
     const int64_t img_elems = (int64_t)g->nc * 64 * 64;
     const bool h3 = g->precision == 1;
-    static const bool no_fuse = getenv("GL_NO_FUSE_TAIL") != nullptr;          // A/B switch
-    const bool fuse_tail = h3 && g->tail_w != nullptr && !no_fuse;
+    const bool fuse_tail = h3 && g->tail_w != nullptr && g->fuse_tail;
     if (h3) {
         rc = dcgan_prepare_h3(g);
         if (rc != GL_OK) return rc;

@@ -168,6 +168,10 @@ int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass);
  * carried as hi + lo halves (~22 mantissa bits), three fp16 MFMAs per product, fp32 accumulation -- same error class,
  * 2-3x faster.  Stacks with the attention block (VAEGAN) always run mode 0. */
 int gl_dcgan_set_precision(gl_dcgan *g, int mode);
+/* 1 (default): in split-fp16 mode, when the last hidden layer has 64 or 128 channels (features_g = 32 or 64), the 3-channel output layer is computed in that
+ * layer's epilogue and its 32 x 32 x C activations are never written to HBM (-9 % on the DCGAN-64 step); 0: separate launches.  Same values up to fp32
+ * summation order. */
+int gl_dcgan_set_fuse_tail(gl_dcgan *g, int on);
 /* VAEGAN generator (gan_models/vaegan/train.py:109-135) = the same ConvTranspose stack with features_g = d/2, plus:
  * the epilogue of layers 0..3 set directly (the caller folds 1/sigma of SpectralNorm, the ConvTranspose bias and
  * BatchNorm into scale/shift), and SelfAttention (gan_models/vaegan/ops.py:86-120) on the 16 x 16 output of layer 2. */

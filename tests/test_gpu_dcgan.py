@@ -194,3 +194,22 @@ def test_large_pass_tiles_match_small_pass_tiles(gl, synth):
     p.set_chunk(20)
     small = p.forward_device(zp, 3, 1.0, True, False)[0].numpy()
     assert big.shape == (260, 3, 32, 32) and np.array_equal(small, big)
+
+
+def test_fused_tail_matches_separate_launches(gl, synth, oracle):
+    """default: the 128 -> 3 output layer rides in the epilogue of the last hidden layer (its activations are never stored);
+    gl_dcgan_set_fuse_tail(0) runs the two layers separately.  Same values up to fp32 summation order, both within the parity
+    bound of the fp64 oracle; also with 64 channels (features_g = 32)."""
+    from ganleaks_amd._lib import check
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    for fg, tol in ((64, 2e-5), (32, 2e-5)):
+        sd = synth.dcgan_state_dict(1234, features_g=fg)
+        g = Generator(100, 3, fg)
+        g.load_state_dict(sd)
+        z = synth.latent(12, 300)
+        fused = g.forward_device(z, True, False)[0].numpy()
+        check(g.ctx.lib.gl_dcgan_set_fuse_tail(g._ensure(), 0))
+        separate = g.forward_device(z, True, False)[0].numpy()
+        assert np.abs(fused - separate).max() < 2e-6
+        ref = oracle.dcgan_generator_forward(sd, z[:3])
+        assert np.abs(fused[:3] - ref).max() < tol and np.abs(separate[:3] - ref).max() < tol
