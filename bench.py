@@ -151,6 +151,11 @@ def main():
     keys_t = None
     if world > 1:
         keys_t = torch.as_tensor(keys.view((Q,), np.int64), device="cuda:%d" % dev)
+        # communicator set-up (RCCL connects lazily on the first collective of a given size class) belongs to setup, also when --warmup 0
+        warm = torch.zeros(Q, dtype=torch.int64, device="cuda:%d" % dev)
+        dist.all_reduce(warm, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        del warm
     log("[rank %d] setup %.1fs: bank rows [%d,%d) of n_eff=%d, %d queries" % (rank, time.time() - t_setup, lo, hi, n_eff, Q))
 
     ev = [ctx.event() for _ in range(4)]
