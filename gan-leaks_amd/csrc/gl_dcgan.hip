@@ -269,6 +269,9 @@ __global__ void __launch_bounds__(256) sn_finish_kernel(const float *__restrict_
 int ensure_workspace(gl_dcgan *g, int64_t n)
 {
     int64_t want = g->chunk > 0 ? g->chunk : 4096;
+    // one activation tensor is addressed through a 32-bit buffer descriptor: keep the largest (32 x 32 x C3 values of 4 bytes) under 3 GiB
+    const int64_t cap = (int64_t)(0xB0000000ull / ((uint64_t)1024 * g->cout[3] * 4));
+    if (want > cap) want = cap;
     if (n < want) want = n;
     if (want <= g->ws_chunk) return GL_OK;
     GL_HIP(hipStreamSynchronize(g->ctx->stream));

@@ -744,7 +744,11 @@ int lp_upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
 
 int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
 {
-    int64_t want = l->chunk > 0 ? l->chunk : 1024;
+    int64_t want = l->chunk > 0 ? l->chunk : 2048;
+    // the convolution kernels address one activation tensor through a 32-bit buffer descriptor: keep the largest (H x W x 64 values of 4 bytes) under 3 GiB
+    const int64_t cap = (int64_t)(0xB0000000ull / ((uint64_t)H * W * 64 * 4));
+    if (want > cap) want = cap;
+    GL_REQUIRE(want >= 1, "gl_lpips_features: %d x %d images are too large for one pass", H, W);
     if (n < want) want = n;
     if (want <= l->ws_imgs && H == l->ws_H && W == l->ws_W) return GL_OK;
     GL_HIP(hipStreamSynchronize(l->ctx->stream));
