@@ -400,6 +400,8 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
         }
     }
     int64_t want = g->chunk > 0 ? g->chunk : (int64_t)((768ull << 20) / (act * 4));   // ~768 MiB per buffer by default
+    const int64_t cap = (int64_t)(0xB0000000ull / (act * 4));                           // 32-bit buffer descriptors: one activation tensor < 3 GiB
+    if (want > cap) want = cap;
     if (want < 1) want = 1;
     if (want > n) want = n;
     const size_t rgb_elems = (size_t)R * R * 4;      // up to 4 floats per pixel (split path pads 3 -> 4)
