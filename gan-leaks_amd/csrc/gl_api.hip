@@ -44,6 +44,7 @@ extern "C" {
 
 int gl_prof_enable(gl_ctx *ctx, int on)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx, "gl_prof_enable: NULL ctx");
     ctx->prof_on = on != 0;
     return GL_OK;
@@ -51,6 +52,7 @@ int gl_prof_enable(gl_ctx *ctx, int on)
 
 int gl_prof_read(gl_ctx *ctx, int tag, double *out_total_ms, int64_t *out_launches)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out_total_ms && out_launches, "gl_prof_read: NULL argument");
     GL_HIP(hipStreamSynchronize(ctx->stream));
     double total = 0.0;
@@ -69,6 +71,7 @@ int gl_prof_read(gl_ctx *ctx, int tag, double *out_total_ms, int64_t *out_launch
 
 int gl_prof_reset(gl_ctx *ctx)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx, "gl_prof_reset: NULL ctx");
     GL_HIP(hipStreamSynchronize(ctx->stream));
     for (const gl_prof_span &s : ctx->prof_spans) {
@@ -125,6 +128,7 @@ int gl_ctx_create(int device, gl_ctx **out_ctx)
 
 int gl_ctx_destroy(gl_ctx *ctx)
 {
+    gl_make_current(ctx);
     if (!ctx) return GL_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -139,6 +143,7 @@ int gl_ctx_destroy(gl_ctx *ctx)
 
 int gl_ctx_set_stream(gl_ctx *ctx, void *hip_stream)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx, "gl_ctx_set_stream: NULL ctx");
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return GL_OK;
@@ -146,6 +151,7 @@ int gl_ctx_set_stream(gl_ctx *ctx, void *hip_stream)
 
 int gl_ctx_get_stream(gl_ctx *ctx, void **out_hip_stream)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out_hip_stream, "gl_ctx_get_stream: NULL argument");
     *out_hip_stream = (void *)ctx->stream;
     return GL_OK;
@@ -153,6 +159,7 @@ int gl_ctx_get_stream(gl_ctx *ctx, void **out_hip_stream)
 
 int gl_ctx_sync(gl_ctx *ctx)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx, "gl_ctx_sync: NULL ctx");
     GL_HIP(hipStreamSynchronize(ctx->stream));
     return GL_OK;
@@ -160,6 +167,7 @@ int gl_ctx_sync(gl_ctx *ctx)
 
 int gl_ctx_h3_saturations(gl_ctx *ctx, int64_t *out_count)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out_count, "gl_ctx_h3_saturations: NULL argument");
     int host = 0;
     GL_HIP(hipMemcpyAsync(&host, ctx->h3_sat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -171,6 +179,7 @@ int gl_ctx_h3_saturations(gl_ctx *ctx, int64_t *out_count)
 
 int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out_dev, "gl_malloc: NULL argument");
     GL_HIP(hipSetDevice(ctx->device));
     *out_dev = nullptr;
@@ -181,6 +190,7 @@ int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev)
 
 int gl_free(gl_ctx *ctx, void *dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx, "gl_free: NULL ctx");
     if (!dev) return GL_OK;
     GL_HIP(hipStreamSynchronize(ctx->stream));
@@ -190,6 +200,7 @@ int gl_free(gl_ctx *ctx, void *dev)
 
 int gl_memcpy_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && (bytes == 0 || (dst_dev && src_host)), "gl_memcpy_h2d: NULL argument");
     if (bytes == 0) return GL_OK;
     GL_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -199,6 +210,7 @@ int gl_memcpy_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes
 
 int gl_memcpy_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && (bytes == 0 || (dst_host && src_dev)), "gl_memcpy_d2h: NULL argument");
     if (bytes == 0) return GL_OK;
     GL_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -208,6 +220,7 @@ int gl_memcpy_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
 
 int gl_memset(gl_ctx *ctx, void *dev, int value, size_t bytes)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && (bytes == 0 || dev), "gl_memset: NULL argument");
     if (bytes == 0) return GL_OK;
     GL_HIP(hipMemsetAsync(dev, value, bytes, ctx->stream));
@@ -232,6 +245,7 @@ int gl_event_destroy(void *event)
 
 int gl_event_record(gl_ctx *ctx, void *event)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && event, "gl_event_record: NULL argument");
     GL_HIP(hipEventRecord((hipEvent_t)event, ctx->stream));
     return GL_OK;

@@ -222,11 +222,13 @@ static int decode_impl(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float 
 
 int gl_encode_lattice_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev)
 {
+    gl_make_current(ctx);
     return encode_impl(ctx, x_dev, count, u8_dev, off_lattice_dev, false);
 }
 
 int gl_encode_integers_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8_t *u8_dev, int32_t *off_lattice_dev)
 {
+    gl_make_current(ctx);
     return encode_impl(ctx, x_dev, count, u8_dev, off_lattice_dev, true);
 }
 
@@ -236,6 +238,7 @@ int gl_decode_u8_integers(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, flo
 
 int gl_quantize_f32(gl_ctx *ctx, const float *x_dev, int64_t count, int mode, uint8_t *u8_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && count >= 0 && (mode == 0 || mode == 1), "gl_quantize_f32: bad ctx/count/mode");
     if (count == 0) return GL_OK;
     GL_REQUIRE(x_dev && u8_dev, "gl_quantize_f32: NULL device pointer");
@@ -250,6 +253,7 @@ int64_t gl_l2_row_stride(int64_t d) { return d <= 0 ? 0 : gl_ceil_div(d, 128) * 
 
 int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_t d, int8_t *rows_i8_dev, int32_t *norms_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && count >= 0 && d > 0, "gl_l2_prepare: bad ctx/count/d");
     // sum (u-128)^2 <= 128^2 * d must fit int32 together with the cross term (see gl_l2knn.hip)
     GL_REQUIRE(d <= GL_L2_MAX_D, "gl_l2_prepare: d=%lld exceeds the exact-integer limit %lld", (long long)d, (long long)GL_L2_MAX_D);
@@ -268,6 +272,7 @@ int gl_l2_prepare(gl_ctx *ctx, const uint8_t *rows_u8_dev, int64_t count, int64_
 
 int gl_l2_rows_u8(gl_ctx *ctx, const uint8_t *x_hat_u8_dev, int64_t b, const uint8_t *x_gt_u8_dev, int64_t b_gt, int64_t d, float *out_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && b >= 0 && d > 0 && d <= GL_L2_MAX_D, "gl_l2_rows_u8: bad ctx/b/d");
     GL_REQUIRE(b_gt == 1 || b_gt == b, "gl_l2_rows_u8: x_gt must hold 1 row or %lld rows (broadcast rule of utils.py:163), got %lld", (long long)b,
                (long long)b_gt);
@@ -283,6 +288,7 @@ int gl_l2_rows_u8(gl_ctx *ctx, const uint8_t *x_hat_u8_dev, int64_t b, const uin
 
 int gl_keys_init(gl_ctx *ctx, uint64_t *keys_dev, int64_t nq)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && nq >= 0, "gl_keys_init: bad ctx/nq");
     if (nq == 0) return GL_OK;
     GL_REQUIRE(keys_dev, "gl_keys_init: NULL keys");
@@ -292,6 +298,7 @@ int gl_keys_init(gl_ctx *ctx, uint64_t *keys_dev, int64_t nq)
 
 int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d, float *dist_dev, int64_t *idx_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && nq >= 0 && d > 0, "gl_keys_unpack: bad ctx/nq/d");
     if (nq == 0) return GL_OK;
     GL_REQUIRE(keys_dev && dist_dev && idx_dev, "gl_keys_unpack: NULL device pointer");
@@ -303,6 +310,7 @@ int gl_keys_unpack(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d,
 
 int gl_keys_unpack_integers(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, int64_t d, float *dist_dev, int64_t *idx_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && nq >= 0 && d > 0, "gl_keys_unpack_integers: bad ctx/nq/d");
     if (nq == 0) return GL_OK;
     GL_REQUIRE(keys_dev && dist_dev && idx_dev, "gl_keys_unpack_integers: NULL device pointer");

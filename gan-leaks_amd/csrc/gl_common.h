@@ -63,6 +63,15 @@ void gl_set_error(const char *fmt, ...);
 
 static inline int64_t gl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// every entry point runs on its context's device, whatever device the calling thread had current (a host thread may drive several contexts,
+// and PyTorch may have switched devices in between)
+static inline void gl_make_current(const gl_ctx *ctx)
+{
+    if (!ctx) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != ctx->device) (void)hipSetDevice(ctx->device);
+}
+
 // run `body` once per device ordinal (function attributes such as the dynamic-LDS limit are per device, and a process may hold
 // contexts on several GPUs); `body` may use GL_HIP (returns on error; the lock is released by the guard)
 #define GL_ONCE_PER_DEVICE(ctx, body)                                                        \

@@ -361,6 +361,7 @@ int launch_gather(gl_ctx *ctx, const GlGatherConv &p, int phases)
 
 int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
+    gl_make_current(ctx);
     GlGatherConv p = p_in;
     {
         const uint64_t imgs = (uint64_t)(p.positions / ((int64_t)p.H * p.W));
@@ -390,6 +391,7 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 int gl_launch_col2im_rgb_tanh(gl_ctx *ctx, const float *P, int64_t ldp, int64_t n_img, int H, int W, const float *bias, float *out_f32,
                               uint8_t *out_u8)
 {
+    gl_make_current(ctx);
     if (n_img == 0) return GL_OK;
     const int64_t total = n_img * H * W;
     gl_prof_scope prof_(ctx, GL_PROF_CONVT_RGB);

@@ -339,6 +339,7 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
+    gl_make_current(ctx);
     GlGatherConv p = p_in;
     p.sat_flag = ctx->h3_sat;
     GL_REQUIRE(p.Cin % 32 == 0, "gather_conv_h3: Cin=%d must be a multiple of 32", p.Cin);
@@ -371,6 +372,7 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 
 int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out)
 {
+    gl_make_current(ctx);
     if (n == 0) return GL_OK;
     GL_REQUIRE(dpad % 32 == 0 && d <= dpad, "split_rows: bad padding");
     hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)gl_ceil_div(n * dpad, 256)), dim3(256), 0, ctx->stream, in, n, d, dpad, scale, reinterpret_cast<char *>(out));

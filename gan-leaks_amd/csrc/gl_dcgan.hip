@@ -305,6 +305,7 @@ extern "C" {
 
 int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl_dcgan **out)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out, "gl_dcgan_create: NULL argument");
     GL_REQUIRE(z_dim > 0 && z_dim <= 4096, "gl_dcgan_create: z_dim=%d unsupported", z_dim);
     GL_REQUIRE(channels_img == 3, "gl_dcgan_create: channels_img=%d unsupported (the RGB tail kernel writes 3 channels)", channels_img);
@@ -350,6 +351,7 @@ int gl_dcgan_create(gl_ctx *ctx, int z_dim, int channels_img, int features_g, gl
 
 int gl_dcgan_destroy(gl_dcgan *g)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     if (!g) return GL_OK;
     (void)hipStreamSynchronize(g->ctx->stream);
     for (int l = 0; l < 5; ++l) (void)hipFree(g->wpack[l]);
@@ -371,6 +373,7 @@ int gl_dcgan_destroy(gl_dcgan *g)
 
 int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && images_per_pass >= 0, "gl_dcgan_set_chunk: bad argument");
     g->chunk = images_per_pass;
     return GL_OK;
@@ -378,6 +381,7 @@ int gl_dcgan_set_chunk(gl_dcgan *g, int64_t images_per_pass)
 
 int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && w && layer >= 0 && layer < 5, "gl_dcgan_set_conv_weight: bad argument");
     const int ci_n = g->cin[layer], co_n = g->cout[layer];
     auto W = [&](int ci, int co, int ky, int kx) { return w[(((int64_t)ci * co_n + co) * 4 + ky) * 4 + kx]; };
@@ -450,6 +454,7 @@ int gl_dcgan_set_conv_weight(gl_dcgan *g, int layer, const float *w)
 
 int gl_dcgan_set_bn(gl_dcgan *g, int layer, const float *gamma, const float *beta, const float *mean, const float *var, float eps)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && gamma && beta && mean && var && layer >= 0 && layer < 4, "gl_dcgan_set_bn: bad argument");
     const int c = g->cout[layer];
     std::vector<float> sc(c), sh(c);
@@ -472,6 +477,7 @@ int gl_dcgan_set_bn(gl_dcgan *g, int layer, const float *gamma, const float *bet
 
 int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && bias, "gl_dcgan_set_out_bias: bad argument");
     std::vector<float> b(bias, bias + g->nc);
     int rc = upload(g->ctx, &g->bias_out, b);
@@ -484,6 +490,7 @@ int gl_dcgan_set_out_bias(gl_dcgan *g, const float *bias)
  * BatchNorm into it (VAEGAN: 1/sigma of the spectral norm and the ConvTranspose bias, gan_models/vaegan/train.py:112-135). */
 int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale, const float *shift)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && scale && shift && layer >= 0 && layer < 4, "gl_dcgan_set_affine: bad argument");
     const int c = g->cout[layer];
     int rc = upload(g->ctx, &g->scale[layer], std::vector<float>(scale, scale + c));
@@ -504,6 +511,7 @@ int gl_dcgan_set_affine(gl_dcgan *g, int layer, const float *scale, const float 
 int gl_dcgan_set_spectral_norm(gl_dcgan *g, int layer, const float *w_bar, const float *u, const float *v, const float *bn_scale, const float *shift,
                                int power_iterations)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && w_bar && u && v && bn_scale && shift && layer >= 0 && layer < 4 && power_iterations >= 1, "gl_dcgan_set_spectral_norm: bad argument");
     int rc = gl_dcgan_set_conv_weight(g, layer, w_bar);
     if (rc != GL_OK) return rc;
@@ -522,6 +530,7 @@ int gl_dcgan_set_spectral_norm(gl_dcgan *g, int layer, const float *w_bar, const
 
 int gl_dcgan_set_spectral_hold(gl_dcgan *g, int hold)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g, "gl_dcgan_set_spectral_hold: NULL generator");
     g->sn_hold = hold != 0;
     return GL_OK;
@@ -529,6 +538,7 @@ int gl_dcgan_set_spectral_hold(gl_dcgan *g, int hold)
 
 int gl_dcgan_get_spectral_state(gl_dcgan *g, int layer, float *u_host, float *v_host)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && layer >= 0 && layer < 4 && g->have_sn[layer] && u_host && v_host, "gl_dcgan_get_spectral_state: bad argument / layer has no spectral norm");
     GL_HIP(hipMemcpyAsync(u_host, g->sn_u[layer], (size_t)g->cin[layer] * 4, hipMemcpyDeviceToHost, g->ctx->stream));
     GL_HIP(hipMemcpyAsync(v_host, g->sn_v[layer], (size_t)g->cout[layer] * 16 * 4, hipMemcpyDeviceToHost, g->ctx->stream));
@@ -540,6 +550,7 @@ int gl_dcgan_get_spectral_state(gl_dcgan *g, int layer, float *u_host, float *v_
  * value conv weight [C2][C2] (1x1 convs), biases, gamma.  gan_models/vaegan/ops.py:86-120. */
 int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const float *wk, const float *bk, const float *wv, const float *bv, float gamma)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && wq && bq && wk && bk && wv && bv, "gl_dcgan_set_attention: NULL argument");
     const int C = g->cout[2], DK = C / 8;
     GL_REQUIRE(C == 64 || C == 128, "gl_dcgan_set_attention: attention width %d unsupported (64 or 128)", C);
@@ -580,6 +591,7 @@ int gl_dcgan_set_attention(gl_dcgan *g, const float *wq, const float *bq, const 
  * epilogue and its activations are never stored; off: the two layers run as separate launches (same values up to fp32 summation order). */
 int gl_dcgan_set_fuse_tail(gl_dcgan *g, int on)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g, "gl_dcgan_set_fuse_tail: NULL generator");
     g->fuse_tail = on != 0;
     return GL_OK;
@@ -587,6 +599,7 @@ int gl_dcgan_set_fuse_tail(gl_dcgan *g, int on)
 
 int gl_dcgan_set_precision(gl_dcgan *g, int mode)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && (mode == 0 || mode == 1), "gl_dcgan_set_precision: mode must be 0 or 1");
     g->precision = mode;
     return GL_OK;
@@ -613,6 +626,7 @@ static int dcgan_prepare_h3(gl_dcgan *g)
 
 int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_dev, uint8_t *out_u8_dev)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && n >= 0, "gl_dcgan_forward: bad argument");
     for (int l = 0; l < 5; ++l)
         if (!g->have_w[l] || (l < 4 && !g->have_bn[l])) {

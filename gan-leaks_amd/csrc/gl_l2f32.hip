@@ -140,6 +140,7 @@ extern "C" {
 int gl_l2_knn_f32(gl_ctx *ctx, const float *bank_dev, int64_t n_rows, int64_t index_base, const float *query_dev, int64_t nq, int64_t d,
                   uint64_t *keys_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && d > 0, "gl_l2_knn_f32: bad sizes");
     GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_l2_knn_f32: global index does not fit 32 bits");
     if (n_rows == 0 || nq == 0) return GL_OK;
@@ -154,6 +155,7 @@ int gl_l2_knn_f32(gl_ctx *ctx, const float *bank_dev, int64_t n_rows, int64_t in
 
 int gl_l2_rows_f32(gl_ctx *ctx, const float *x_hat_dev, int64_t b, const float *x_gt_dev, int64_t b_gt, int64_t d, float *out_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && b >= 0 && d > 0, "gl_l2_rows_f32: bad ctx/b/d");
     GL_REQUIRE(b_gt == 1 || b_gt == b, "gl_l2_rows_f32: x_gt must hold 1 row or %lld rows, got %lld", (long long)b, (long long)b_gt);
     if (b == 0) return GL_OK;
@@ -165,6 +167,7 @@ int gl_l2_rows_f32(gl_ctx *ctx, const float *x_hat_dev, int64_t b, const float *
 
 int gl_keys_unpack_f32(gl_ctx *ctx, const uint64_t *keys_dev, int64_t nq, float *dist_dev, int64_t *idx_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && nq >= 0, "gl_keys_unpack_f32: bad ctx/nq");
     if (nq == 0) return GL_OK;
     GL_REQUIRE(keys_dev && dist_dev && idx_dev, "gl_keys_unpack_f32: NULL device pointer");

@@ -272,6 +272,7 @@ extern "C" {
 int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_norm_dev, int64_t n_rows, int64_t index_base,
                  const int8_t *query_i8_dev, const int32_t *query_norm_dev, int64_t nq, int64_t d, uint64_t *keys_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx, "gl_l2_knn_i8: NULL ctx");
     GL_REQUIRE(n_rows >= 0 && nq >= 0 && d > 0 && d <= GL_L2_MAX_D, "gl_l2_knn_i8: bad sizes n_rows=%lld nq=%lld d=%lld (d <= %lld)", (long long)n_rows,
                (long long)nq, (long long)d, (long long)GL_L2_MAX_D);
@@ -312,6 +313,7 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
 int gl_fbb_knn_l2_host(gl_ctx *ctx, const uint8_t *bank_u8_host, int64_t n_bank, const uint8_t *queries_u8_host, int64_t nq, int64_t d,
                        int64_t batch_size, float *dist_host, int64_t *idx_host)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && n_bank >= 0 && nq >= 0 && d > 0 && batch_size > 0, "gl_fbb_knn_l2_host: bad sizes");
     const int64_t n_eff = (n_bank / batch_size) * batch_size;   // attack_models/fbb.py:77
     if (n_eff == 0) {

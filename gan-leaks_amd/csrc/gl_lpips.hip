@@ -894,6 +894,7 @@ extern "C" {
 
 int gl_lpips_create(gl_ctx *ctx, gl_lpips **out)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out, "gl_lpips_create: NULL argument");
     gl_lpips *l = new gl_lpips();
     l->ctx = ctx;
@@ -912,6 +913,7 @@ int gl_lpips_create(gl_ctx *ctx, gl_lpips **out)
 
 int gl_lpips_destroy(gl_lpips *l)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     if (!l) return GL_OK;
     (void)hipStreamSynchronize(l->ctx->stream);
     for (int i = 0; i < kNumConv; ++i) { (void)hipFree(l->w[i]); (void)hipFree(l->bias[i]); (void)hipFree(l->wsplit[i]); (void)hipFree(l->scale_h3[i]); (void)hipFree(l->bias_h3[i]); }
@@ -923,6 +925,7 @@ int gl_lpips_destroy(gl_lpips *l)
 
 int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     GL_REQUIRE(l && images_per_pass >= 0, "gl_lpips_set_chunk: bad argument");
     l->chunk = images_per_pass;
     return GL_OK;
@@ -930,6 +933,7 @@ int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass)
 
 int gl_lpips_set_precision(gl_lpips *l, int mode)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     GL_REQUIRE(l && (mode == 0 || mode == 1), "gl_lpips_set_precision: mode must be 0 or 1");
     l->precision = mode;
     return GL_OK;
@@ -937,6 +941,7 @@ int gl_lpips_set_precision(gl_lpips *l, int mode)
 
 int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *bias)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     GL_REQUIRE(l && w && bias && conv_index >= 0 && conv_index < kNumConv, "gl_lpips_set_conv: bad argument");
     const int co_n = kCout[conv_index], ci_n = kCin[conv_index];
     auto Wt = [&](int co, int ci, int ky, int kx) { return w[(((int64_t)co * ci_n + ci) * 3 + ky) * 3 + kx]; };
@@ -985,6 +990,7 @@ int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *
 
 int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     GL_REQUIRE(l && w && layer >= 0 && layer < 5, "gl_lpips_set_lin: bad argument");
     for (int c = 0; c < kTapC[layer]; ++c)
         GL_REQUIRE(w[c] >= 0.0f, "gl_lpips_set_lin: lin%d weight %d is negative (%g); the |V_q - V_n|^2 form needs w >= 0", layer, c, (double)w[c]);
@@ -1004,11 +1010,13 @@ int64_t gl_lpips_feature_dim(int H, int W)
 
 int gl_lpips_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V_dev, norms_dev, 0);
 }
 
 int gl_lpips_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, float *V_dev, float *norms_dev)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V_dev, norms_dev, 0);
 }
 
@@ -1022,12 +1030,14 @@ int64_t gl_lpips_search_dim(int H, int W)
 
 int gl_lpips_search_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     GL_REQUIRE(role == 0 || role == 1, "gl_lpips_search_features: role must be 0 (query rows) or 1 (bank rows)");
     return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V16_dev, norms_dev, 1 + role);
 }
 
 int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev)
 {
+    gl_make_current(l ? l->ctx : nullptr);
     GL_REQUIRE(role == 0 || role == 1, "gl_lpips_search_features: role must be 0 (query rows) or 1 (bank rows)");
     return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V16_dev, norms_dev, 1 + role);
 }
@@ -1035,6 +1045,7 @@ int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t 
 int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
                    const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K1 > 0 && K1 % 64 == 0, "gl_feat_knn_h1: bad sizes (K1 must be a multiple of 64)");
     GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn_h1: global index does not fit 32 bits");
     if (n_rows == 0 || nq == 0) return GL_OK;
@@ -1056,6 +1067,7 @@ int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm
 int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
                     const float *query_norm_dev, int64_t nq, int64_t K, uint64_t *keys_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K > 0 && K % 32 == 0, "gl_feat_knn: bad sizes (K must be a multiple of 32)");
     GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn: global index does not fit 32 bits");
     if (n_rows == 0 || nq == 0) return GL_OK;
@@ -1078,6 +1090,7 @@ int64_t gl_rows_split_dim(int64_t d) { return d <= 0 ? 0 : gl_ceil_div(d, 32) * 
 
 int gl_rows_split_f32(gl_ctx *ctx, const float *rows_f32_dev, int64_t n, int64_t d, void *V_dev, float *norms_dev, float *scales_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && n >= 0 && d > 0, "gl_rows_split_f32: bad sizes");
     if (n == 0) return GL_OK;
     GL_REQUIRE(rows_f32_dev && V_dev && norms_dev && scales_dev, "gl_rows_split_f32: NULL device pointer");
@@ -1091,6 +1104,7 @@ int gl_rows_split_f32(gl_ctx *ctx, const float *rows_f32_dev, int64_t n, int64_t
 int gl_rows_knn_split(gl_ctx *ctx, const void *bank_V_dev, const float *bank_norm_dev, const float *bank_scale_dev, int64_t n_rows, int64_t index_base,
                       const void *query_V_dev, const float *query_norm_dev, const float *query_scale_dev, int64_t nq, int64_t d, uint64_t *keys_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && d > 0, "gl_rows_knn_split: bad sizes");
     GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_rows_knn_split: global index does not fit 32 bits");
     if (n_rows == 0 || nq == 0) return GL_OK;
@@ -1112,6 +1126,7 @@ int gl_rows_knn_split(gl_ctx *ctx, const void *bank_V_dev, const float *bank_nor
 int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const float *V_gt_dev, int64_t b_gt, int64_t K, int64_t K_lp, float *out_lpips_dev,
                       float *out_l2_dev)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && b >= 0 && K > 0 && K_lp >= 0 && K_lp <= K && K % 8 == 0 && K_lp % 8 == 0, "gl_feat_rows_dist: bad sizes");
     GL_REQUIRE(b_gt == 1 || b_gt == b, "gl_feat_rows_dist: x_gt must hold 1 row or %lld rows, got %lld", (long long)b, (long long)b_gt);
     if (b == 0) return GL_OK;
@@ -1128,6 +1143,7 @@ int gl_feat_rows_dist(gl_ctx *ctx, const float *V_hat_dev, int64_t b, const floa
 int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host, int64_t n_bank, const uint8_t *queries_u8_host, int64_t nq, int H, int W,
                           int64_t batch_size, int64_t max_device_bytes, float *dist_host, int64_t *idx_host)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && l && l->ctx == ctx && n_bank >= 0 && nq >= 0 && batch_size > 0, "gl_fbb_knn_lpips_host: bad argument");
     const int64_t K1 = gl_lpips_search_dim(H, W);
     GL_REQUIRE(K1 > 0, "gl_fbb_knn_lpips_host: H, W must be multiples of 16, got %dx%d", H, W);

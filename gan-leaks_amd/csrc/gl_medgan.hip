@@ -61,6 +61,7 @@ extern "C" {
 
 int gl_medgan_create(gl_ctx *ctx, int z_dim, int hidden_size, int input_size, int binary, gl_medgan **out)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out, "gl_medgan_create: NULL argument");
     // the reference's residual adds force z_dim == hidden_size == genDim == 128 (model.py:49,66,71)
     GL_REQUIRE(z_dim == 128 && hidden_size == 128, "gl_medgan_create: the residual generator needs z_dim == hidden_size == 128 (model.py:49-71), got %d / %d", z_dim,
@@ -77,6 +78,7 @@ int gl_medgan_create(gl_ctx *ctx, int z_dim, int hidden_size, int input_size, in
 
 int gl_medgan_destroy(gl_medgan *g)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     if (!g) return GL_OK;
     (void)hipStreamSynchronize(g->ctx->stream);
     for (int l = 0; l < 3; ++l) { (void)hipFree(g->w[l]); (void)hipFree(g->scale[l]); (void)hipFree(g->shift[l]); }
@@ -90,6 +92,7 @@ int gl_medgan_destroy(gl_medgan *g)
 int gl_medgan_set_gen_block(gl_medgan *g, int block, const float *lin_w, const float *lin_b, const float *gamma, const float *beta, const float *mean,
                             const float *var, float eps)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && (block == 0 || block == 1) && lin_w && lin_b && gamma && beta && mean && var, "gl_medgan_set_gen_block: bad argument");
     const int in = block == 0 ? g->z_dim : g->hidden, out = 128;
     std::vector<float> sc(out), sh(out);
@@ -109,6 +112,7 @@ int gl_medgan_set_gen_block(gl_medgan *g, int block, const float *lin_w, const f
 /* Autoencoder.decoder.0.{weight [F][hidden], bias [F]} (model.py:28) */
 int gl_medgan_set_decoder(gl_medgan *g, const float *w, const float *b)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && w && b && g->F > 0, "gl_medgan_set_decoder: bad argument (input_size must be > 0)");
     std::vector<float> one(g->F, 1.0f);
     int rc = mg_upload(g->ctx, &g->w[2], pack_linear(w, g->F, g->hidden));
@@ -122,6 +126,7 @@ int gl_medgan_set_decoder(gl_medgan *g, const float *w, const float *b)
 /* Generator.forward: z_dev [n][128] -> hidden_out_dev [n][128] */
 int gl_medgan_generate(gl_medgan *g, const float *z_dev, int64_t n, float *hidden_out_dev)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && n >= 0, "gl_medgan_generate: bad argument");
     if (!g->have_gen) { gl_set_error("gl_medgan_generate: generator blocks not loaded"); return GL_ERR_STATE; }
     if (n == 0) return GL_OK;
@@ -141,6 +146,7 @@ int gl_medgan_generate(gl_medgan *g, const float *z_dev, int64_t n, float *hidde
 /* Autoencoder.decode: hidden_dev [n][128] -> decoded_dev [n][F] (sigmoid or ReLU); binary_dev (optional) = decoded >= 0.5 */
 int gl_medgan_decode(gl_medgan *g, const float *hidden_dev, int64_t n, float *decoded_dev, float *binary_dev)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && n >= 0, "gl_medgan_decode: bad argument");
     if (!g->have_dec) { gl_set_error("gl_medgan_decode: decoder not loaded"); return GL_ERR_STATE; }
     if (n == 0) return GL_OK;

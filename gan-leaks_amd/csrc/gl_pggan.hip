@@ -255,6 +255,7 @@ extern "C" {
 
 int gl_pggan_create(gl_ctx *ctx, int z_dim, int in_channels, int img_channels, gl_pggan **out)
 {
+    gl_make_current(ctx);
     GL_REQUIRE(ctx && out, "gl_pggan_create: NULL argument");
     GL_REQUIRE(z_dim > 0 && z_dim <= 4096 && in_channels >= 32 && in_channels % 32 == 0 && img_channels > 0 && img_channels <= 4,
                "gl_pggan_create: unsupported sizes z_dim=%d in_channels=%d (multiple of 32) img_channels=%d", z_dim, in_channels, img_channels);
@@ -285,6 +286,7 @@ int gl_pggan_create(gl_ctx *ctx, int z_dim, int in_channels, int img_channels, g
 
 int gl_pggan_destroy(gl_pggan *g)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     if (!g) return GL_OK;
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->w_init); (void)hipFree(g->b_init); (void)hipFree(g->w_i3); (void)hipFree(g->b_i3); (void)hipFree(g->ones);
@@ -304,6 +306,7 @@ int gl_pggan_destroy(gl_pggan *g)
 
 int gl_pggan_set_precision(gl_pggan *g, int mode)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && (mode == 0 || mode == 1), "gl_pggan_set_precision: mode must be 0 or 1");
     g->precision = mode;
     return GL_OK;
@@ -311,6 +314,7 @@ int gl_pggan_set_precision(gl_pggan *g, int mode)
 
 int gl_pggan_set_chunk(gl_pggan *g, int64_t images_per_pass)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && images_per_pass >= 0, "gl_pggan_set_chunk: bad argument");
     g->chunk = images_per_pass;
     return GL_OK;
@@ -319,6 +323,7 @@ int gl_pggan_set_chunk(gl_pggan *g, int64_t images_per_pass)
 /* initial.1.{weight [z][C][4][4], bias [C]} and initial.3.{conv.weight [C][C][3][3], bias [C]} */
 int gl_pggan_set_initial(gl_pggan *g, const float *convt_w, const float *convt_b, const float *ws_w, const float *ws_b)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && convt_w && convt_b && ws_w && ws_b, "gl_pggan_set_initial: NULL argument");
     const int C = g->C, K = g->z_pad;
     std::vector<float> pk((size_t)16 * C * K, 0.0f);   // GEMM [16*C][z_pad]: column (ky*4+kx)*C + co -> NHWC 4x4xC
@@ -340,6 +345,7 @@ int gl_pggan_set_initial(gl_pggan *g, const float *convt_w, const float *convt_b
 /* prog_blocks.{block}.conv{1,2}.{conv.weight, bias} */
 int gl_pggan_set_block(gl_pggan *g, int block, const float *conv1_w, const float *conv1_b, const float *conv2_w, const float *conv2_b)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && block >= 0 && block < kBlocks && conv1_w && conv1_b && conv2_w && conv2_b, "gl_pggan_set_block: bad argument");
     const int ci = g->cin[block], co = g->cout[block];
     GL_REQUIRE(co >= 1, "gl_pggan_set_block: block %d has no channels at in_channels=%d", block, g->C);
@@ -359,6 +365,7 @@ int gl_pggan_set_block(gl_pggan *g, int block, const float *conv1_w, const float
 /* rgb_layers.{j}.{conv.weight [nc][C_j][1][1], bias [nc]}; j = 0 is initial_rgb */
 int gl_pggan_set_rgb(gl_pggan *g, int j, const float *w, const float *b)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && j >= 0 && j <= kBlocks && w && b, "gl_pggan_set_rgb: bad argument");
     const int ci = rgb_cin(g, j);
     GL_REQUIRE(ci >= 1, "gl_pggan_set_rgb: layer %d has no input channels", j);
@@ -376,6 +383,7 @@ int gl_pggan_set_rgb(gl_pggan *g, int j, const float *w, const float *b)
  * out_u8_dev = the bytes pggan/train.py:238-246 writes (x*0.5+0.5, mul(255).byte()).  Either may be NULL. */
 int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, float alpha, float *out_f32_dev, uint8_t *out_u8_dev)
 {
+    gl_make_current(g ? g->ctx : nullptr);
     GL_REQUIRE(g && n >= 0 && steps >= 0 && steps <= kBlocks, "gl_pggan_forward: bad argument (steps in [0,8])");
     if (!g->have_init) { gl_set_error("gl_pggan_forward: initial block not loaded"); return GL_ERR_STATE; }
     for (int s = 0; s < steps; ++s) {
