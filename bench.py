@@ -54,6 +54,8 @@ def main():
                     help="generator arithmetic: 1 = split-fp16 (three fp16 MFMAs per product, default), 0 = fp32 MFMA")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal: several ranks may then share one GPU)")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: equal bank shards instead of shards sized by each rank's measured generator speed")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="stop the CPU baseline after this many seconds (at least 8 queries are timed)")
     ap.add_argument("--feat-rows", default="fp16", choices=["fp16", "split"],
                     help="l2-lpips only: rows of the nearest-neighbour search: fp16 = one half per LPIPS value (gl_feat_knn_h1, default), "
@@ -110,6 +112,33 @@ def main():
         gen.set_chunk(args.chunk)
     gen.set_precision(args.gen_precision)
     z_all = synth.latent(1, N)                               # the bank's latents; bank index = z index
+    shard_note = "equal shards"
+    if world > 1 and not args.no_balance:
+        # The GPUs of a node do not run matrix-core loops at the same clock (MI355X_MICROARCH.md: 12 % device-to-device) and the slowest rank
+        # sets the step time.  Setup: every rank times the generator on the same 4096 latents, the bank is then cut in proportion to the
+        # measured rates.  The result does not depend on the cut (exact keys + min).
+        zc = ctx.to_device(z_all[:4096].reshape(-1, 100))
+        uc = ctx.empty((len(zc), 3, 64, 64), np.uint8)
+        e0, e1 = ctx.event(), ctx.event()
+        times = []
+        for it in range(7):
+            e0.record()
+            check(lib.gl_dcgan_forward(gen._handle, p(zc.ptr), len(zc), p(0), p(uc.ptr)))
+            e1.record()
+            ctx.sync()
+            if it >= 2:
+                times.append(e0.elapsed_ms_until(e1))
+        mine = torch.tensor([float(np.median(times))], dtype=torch.float64)
+        if args.backend == "nccl":
+            mine = mine.cuda()
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        ms = [float(t.item()) for t in allt]
+        bounds = shard.weighted_bounds(n_eff, [1.0 / t for t in ms], B)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        n_loc = hi - lo
+        shard_note = "shards sized by measured generator speed (%s ms per 4096 images)" % ", ".join("%.2f" % t for t in ms)
+        del zc, uc
     z_dev = ctx.to_device(z_all[lo:hi].reshape(n_loc, 100))
     # queries: both classes are fresh generator samples (z streams disjoint from the bank's) with pixel noise;
     # members get the smaller noise, so they sit closer to the bank on average and the AUROC is non-degenerate
@@ -367,8 +396,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)" if lp_model is None else
                        "BASELINE configs[2] shape: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",
                        "queries": Q, "bank": N,
-                       "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d, queries replicated, "
-                       "all-reduce(min) of %d packed keys" % (world, Q) if world > 1 else "single GPU"},
+                       "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d (%s), queries replicated, "
+                       "all-reduce(min) of %d packed keys" % (world, shard_note, Q) if world > 1 else "single GPU",
+                       "shard_rows": [int(bounds[r + 1] - bounds[r]) for r in range(world)]},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,

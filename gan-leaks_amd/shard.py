@@ -21,6 +21,21 @@ def shard_bounds(n_total, batch_size, world):
     return [n_eff * r // world for r in range(world + 1)]
 
 
+def weighted_bounds(n_eff, weights, multiple=64):
+    """contiguous ranges of [0, n_eff) with sizes proportional to `weights` (e.g. measured rows/s of every rank: the GPUs of one node
+    differ by up to ~12 % under matrix-core load, and the slowest rank sets the step time), interior boundaries rounded to `multiple`.
+    The result of the attack does not depend on the split.  returns list of len(weights)+1 ints."""
+    w = np.asarray(weights, np.float64)
+    if w.ndim != 1 or len(w) == 0 or not np.all(np.isfinite(w)) or np.any(w <= 0):
+        raise ValueError("weights must be positive finite numbers")
+    cum = np.concatenate([[0.0], np.cumsum(w)]) / w.sum()
+    b = [int(round(c * n_eff / multiple)) * multiple for c in cum]
+    b[0], b[-1] = 0, int(n_eff)
+    for r in range(1, len(b)):                        # monotone, inside the range
+        b[r] = min(max(b[r], b[r - 1]), int(n_eff))
+    return b
+
+
 def merge_keys_host(key_arrays):
     """reference semantics of the reduce, on host arrays (used by tests and the gloo path)."""
     out = np.asarray(key_arrays[0], np.uint64).copy()

@@ -70,3 +70,21 @@ def test_shard_bounds_global_truncation():
     assert b[0] == 0 and b[-1] == 990 and all(b[k] <= b[k + 1] for k in range(7))
     k = [np.array([5, 9], np.uint64), np.array([7, 2], np.uint64), np.array([6, 3], np.uint64)]
     assert shard.merge_keys_host(k).tolist() == [5, 2]
+
+
+def test_weighted_bounds():
+    """shards proportional to measured rank speeds: contiguous, cover [0, n_eff), interior cuts on multiples of the batch size"""
+    import ganleaks_amd  # noqa: F401
+    from ganleaks_amd import shard
+    b = shard.weighted_bounds(99968, [1.0] * 8, 64)
+    assert b[0] == 0 and b[-1] == 99968 and all(x % 64 == 0 for x in b) and max(np.diff(b)) - min(np.diff(b)) <= 64
+    w = [1 / 8.3, 1 / 7.5, 1 / 8.0, 1 / 7.9]
+    b = shard.weighted_bounds(99968, w, 64)
+    sizes = np.diff(b)
+    assert b[0] == 0 and b[-1] == 99968 and (sizes > 0).all() and all(x % 64 == 0 for x in b[:-1])
+    assert np.abs(sizes / 99968 - np.array(w) / sum(w)).max() < 1e-3
+    assert np.argmax(sizes) == 1 and np.argmin(sizes) == 0
+    assert shard.weighted_bounds(128, [1, 1, 1], 64) in ([0, 64, 64, 128], [0, 64, 128, 128], [0, 0, 64, 128])
+    for bad in ([], [1, 0], [1, float("nan")]):
+        with pytest.raises(ValueError):
+            shard.weighted_bounds(100, bad)
