@@ -93,3 +93,38 @@ def test_generate_branch_png_bank_and_sweep(tmp_path, monkeypatch, synth):
         d_direct, i_direct = gl.attack(queries, banks[tag][bank_io.generation_order(bank_io.load_png_bank(str(sweep / tag), 64)[1])], batch_size=64)
         assert np.array_equal(nn, i_direct)
         assert np.array_equal(np.load(out / "pos_loss.npy")[:, 0], d_direct.astype(np.float64))
+
+
+def test_generate_branch_command_line(tmp_path, synth, oracle):
+    """the generate branch of gan_models/dcgan/train_torch.py (:138-174): generator.pth -> npz_images / npz_noise / png_images/<timestamp>,
+    driven through a YAML config like the reference's; the PNG bank is what fbb.py then reads"""
+    import subprocess
+    import sys
+    import torch
+    import yaml
+    from ganleaks_amd import bank_io
+    from ganleaks_amd.gan_models.dcgan import train_torch
+    model_dir = tmp_path / "model"
+    model_dir.mkdir()
+    sd = synth.dcgan_state_dict(1234)
+    torch.save({k: torch.from_numpy(v) for k, v in sd.items()}, model_dir / "generator.pth")
+    cfg = {"training": False, "generate": True, "saved_model_name": str(model_dir), "num_generated": 70, "PATH_syn_data": str(tmp_path / "syn")}
+    (tmp_path / "gen.yaml").write_text(yaml.safe_dump(cfg))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, "-m", "ganleaks_amd.gan_models.dcgan.train_torch", "--local_config", str(tmp_path / "gen.yaml")], check=True,
+                   cwd=root)
+    stamps = os.listdir(tmp_path / "syn" / "png_images")
+    assert len(stamps) == 1 and stamps[0].startswith("_20")
+    fake = np.load(tmp_path / "syn" / "npz_images" / stamps[0] / "dcgan_synthetic_data.npz")["fake"]
+    noise = np.load(tmp_path / "syn" / "npz_noise" / stamps[0] / "dcgan_noise.npz")["noise"]
+    assert fake.shape == (70, 3, 64, 64) and fake.dtype == np.float32 and noise.shape == (70, 100, 1, 1)
+    ref = oracle.dcgan_generator_forward(sd, noise[:3])
+    assert np.abs((fake[:3] * 2 - 1) - ref).max() < 2e-5 and fake.min() >= 0 and fake.max() <= 1
+    bank, paths = bank_io.load_png_bank(str(tmp_path / "syn" / "png_images" / stamps[0]), 64)
+    order = bank_io.generation_order(paths)
+    # ToPILImage: the [0,1] float image times 255, truncated (train_torch.py:172): the PNG bytes are exactly that of the saved `fake`
+    assert np.array_equal(bank, np.clip(np.floor(fake * np.float32(255.0)), 0, 255).astype(np.uint8)[order])
+    args = train_torch.parse_arguments([])
+    args.training = True
+    with pytest.raises(NotImplementedError):
+        train_torch.main(args)
