@@ -14,12 +14,11 @@ Training (`--training`) is outside this repository's scope and is refused.  As i
 from __future__ import annotations
 
 import argparse
-import datetime
 import os
 
 import numpy as np
 
-from ...bank_io import save_png_bank
+from .._generate import refuse_training, run_cli, run_generate
 from .model_torch import Generator
 
 
@@ -58,53 +57,20 @@ def update_args(args, config_dict):
         setattr(args, key, val)
 
 
-def generate(args, noise=None, timestamp=None, pass_images=16384):
+def generate(args, noise=None, timestamp=None):
     """train_torch.py:138-174.  Returns (png_dir, npz_images_path, npz_noise_path)."""
-    import torch
-    if args.saved_model_name is None:
-        raise AssertionError("Please specify the saved model name")
-    if args.wandb is not None:
-        raise AssertionError("No need to load anything to wand when only generating synthetic data")
-    gen = Generator(args.nz, args.nc, args.ngf)
-    gen.load_state_dict(torch.load(os.path.join(args.saved_model_name, "generator.pth"), map_location="cpu", weights_only=True))
-    gen.eval()
-    if noise is None:
-        noise = torch.randn(args.num_generated, args.nz, 1, 1)
-    noise_np = noise.numpy() if hasattr(noise, "numpy") else np.asarray(noise, np.float32)
-    n = len(noise_np)
-    fake = np.empty((n, args.nc, 64, 64), np.float32)
-    codes = np.empty((n, args.nc, 64, 64), np.uint8)
-    for lo in range(0, n, pass_images):                    # the reference runs all N in one forward (52 GB of activations at 100k)
-        f32, u8 = gen.forward_device(noise_np[lo:lo + pass_images], True, True)
-        x = f32.numpy()
-        fake[lo:lo + len(x)] = (x + np.float32(1.0)) / np.float32(2.0)          # Normalize(mean=-1, std=2)
-        codes[lo:lo + len(x)] = u8.numpy()
-    timestamp = timestamp or datetime.datetime.now().strftime("_%Y_%m_%d__%H_%M_%S")
-    d_img = os.path.join(args.PATH_syn_data, 'npz_images', timestamp)
-    d_noise = os.path.join(args.PATH_syn_data, 'npz_noise', timestamp)
-    d_png = os.path.join(args.PATH_syn_data, 'png_images', timestamp)
-    os.makedirs(d_img, exist_ok=True)
-    np.savez(os.path.join(d_img, "dcgan_synthetic_data.npz"), fake=fake)
-    os.makedirs(d_noise, exist_ok=True)
-    np.savez(os.path.join(d_noise, "dcgan_noise.npz"), noise=noise_np)
-    save_png_bank(codes, d_png)
-    return d_png, os.path.join(d_img, "dcgan_synthetic_data.npz"), os.path.join(d_noise, "dcgan_noise.npz")
+    return run_generate(args, Generator(args.nz, args.nc, args.ngf), args.num_generated, lambda g, z: g.forward_device(z, True, True),
+                        lambda x: (x + np.float32(1.0)) / np.float32(2.0),            # Normalize(mean=-1, std=2)
+                        "dcgan_synthetic_data.npz", "dcgan_noise.npz", noise, timestamp)
 
 
 def main(args):
     print(args)
-    if args.training:
-        raise NotImplementedError("training is outside the scope of this repository (the generate branch needs --training False, set it in "
-                                  "the YAML config: argparse's type=bool turns any command-line string into True)")
+    refuse_training(args)
     if args.generate:
         return generate(args)
     return None
 
 
 if __name__ == '__main__':
-    a = parse_arguments()
-    if a.local_config is not None:
-        import yaml
-        with open(str(a.local_config), "r") as f:
-            update_args(a, yaml.safe_load(f))
-    main(a)
+    run_cli(parse_arguments, main)

@@ -128,3 +128,33 @@ def test_generate_branch_command_line(tmp_path, synth, oracle):
     args.training = True
     with pytest.raises(NotImplementedError):
         train_torch.main(args)
+
+
+def test_generate_branches_wgangp_and_pggan(tmp_path, synth):
+    """wgangp/train.py:139-174 (draws `batch_size` images) and pggan/train.py:205-257 (gen(noise, 4, 1) * 0.5 + 0.5)"""
+    import torch
+    from ganleaks_amd import bank_io
+    from ganleaks_amd.gan_models.pggan import train as pg_train
+    from ganleaks_amd.gan_models.wgangp import train as wg_train
+    wdir = tmp_path / "w"
+    wdir.mkdir()
+    torch.save({k: torch.from_numpy(v) for k, v in synth.dcgan_state_dict(77).items()}, wdir / "generator.pth")
+    a = wg_train.parse_arguments(["--saved_model_name", str(wdir), "--PATH_syn_data", str(tmp_path / "wsyn"), "--batch_size", "33"])
+    png, npz_i, npz_n = wg_train.main(a)
+    fake = np.load(npz_i)["fake"]
+    assert os.path.basename(npz_i) == "wgangp_synthetic_data.npz" and os.path.basename(npz_n) == "wgangp_noise.npz" and fake.shape == (33, 3, 64, 64)
+    bank, paths = bank_io.load_png_bank(png, 64)
+    assert np.array_equal(bank, np.clip(np.floor(fake * np.float32(255.0)), 0, 255).astype(np.uint8)[bank_io.generation_order(paths)])
+    pdir = tmp_path / "p"
+    pdir.mkdir()
+    torch.save({k: torch.from_numpy(v) for k, v in synth.pggan_state_dict(5, 128, 128).items()}, pdir / "generator.pth")
+    a = pg_train.parse_arguments(["--saved_model_name", str(pdir), "--PATH_syn_data", str(tmp_path / "psyn"), "--num_generated", "21", "--nz", "128",
+                                  "--in_channels", "128"])
+    png, npz_i, npz_n = pg_train.main(a)
+    fake = np.load(npz_i)["fake"]
+    assert os.path.basename(npz_i) == "pggan_images.npz" and fake.shape == (21, 3, 64, 64) and np.load(npz_n)["noise"].shape == (21, 128, 1, 1)
+    bank, paths = bank_io.load_png_bank(png, 64)
+    assert np.array_equal(bank, np.clip(np.floor(fake * np.float32(255.0)), 0, 255).astype(np.uint8)[bank_io.generation_order(paths)])
+    a.training = True
+    with pytest.raises(NotImplementedError):
+        pg_train.main(a)
