@@ -51,3 +51,28 @@ def test_vaegan_oracle_and_chunks(synth):
     gen3.load_state_dict(sd)
     gen3.set_precision(0)
     assert np.abs(gen3(z) - out).max() < 2e-5
+
+
+def test_sample_script(tmp_path, synth):
+    """vaegan/sample.py: seed 1000, batches of 100, one forward (and one spectral-norm step) per batch; generated.npz + samples.png"""
+    import torch
+    from ganleaks_amd.gan_models.vaegan import sample
+    from ganleaks_amd.gan_models.vaegan.train import Generator
+    sd = synth.vaegan_state_dict(779, 64, 32)
+    torch.save({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, tmp_path / "netG.pt")
+    out = sample.main(sample.parse_args(["--model_dir", str(tmp_path), "--num_samples", "150"]))
+    g = np.load(out)
+    assert g["noise"].shape == (150, 64) and g["img_r01"].shape == (150, 64, 64, 3) and g["img_r01"].dtype == np.float32
+    assert (tmp_path / "samples.png").stat().st_size > 1000
+    # the same schedule by hand: two forwards of 100 latents each
+    torch.manual_seed(1000)
+    ref = Generator(64, 32)
+    ref.load_state_dict(sd)
+    z1, z2 = torch.randn(100, 64, 1, 1), torch.randn(100, 64, 1, 1)
+    a, b = ref(z1.numpy()), ref(z2.numpy())
+    assert np.array_equal(g["noise"][:100], z1.numpy().reshape(100, 64))
+    want = (np.concatenate([a, b])[:150] + np.float32(1)) / np.float32(2)
+    assert np.array_equal(g["img_r01"], want.transpose(0, 2, 3, 1))
+    torch.save(torch.nn.Linear(2, 2), tmp_path / "netG.pt")       # a pickled module is refused, not executed
+    with pytest.raises(ValueError):
+        sample.main(sample.parse_args(["--model_dir", str(tmp_path)]))
