@@ -273,6 +273,9 @@ def main():
             # the split-fp16 kernel issues 3 fp16 MFMAs per algorithmic product: matrix-pipe occupancy = 3 x the algorithmic rate
             e["executed_mfma"] = round(achieved * executed_factor, 2)
             e["executed_frac"] = round(achieved * executed_factor / peak, 4)
+            if executed_factor == 3.0:
+                # the arithmetic is fp32-class (22-bit operands, fp32 accumulation): against the fp32 matrix path it replaces
+                e["frac_of_f32_mfma_peak"] = round(achieved / PEAK_F32_MFMA_TFLOPS, 3)
         if note:
             e["note"] = note
         return e
@@ -306,7 +309,7 @@ def main():
                 k["traffic"] = round(tr[k["kernel"]]["hbm_bytes_per_launch"])
     dominant = max(kernels, key=lambda k: k["avg_ms"] * k["launches"])
     roofline = {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    for k in ("executed_mfma", "executed_frac", "note"):
+    for k in ("executed_mfma", "executed_frac", "frac_of_f32_mfma_peak", "note"):
         if k in dominant:
             roofline[k] = dominant[k]
     roofline["kernel"] = dominant["kernel"]
