@@ -28,9 +28,9 @@ def parse_arguments(argv=None):
     p.add_argument('--lr', type=float, default=2e-4)
     p.add_argument('--batch_size', type=int, default=128)
     p.add_argument('--image_size', type=int, default=64)
-    p.add_argument('--nc', type=int, default=3, help='number of color channels in the input image, default=3')
-    p.add_argument('--nz', type=int, default=100, help='size of the latent z vector, default=100')
-    p.add_argument('--ngf', type=int, default=64, help='number of generator filters in first conv layer, default=64')
+    p.add_argument('--nc', type=int, default=3, help='image channels (3)')
+    p.add_argument('--nz', type=int, default=100, help='length of a latent vector')
+    p.add_argument('--ngf', type=int, default=64, help='width parameter of the generator (features_g)')
     p.add_argument('--ndf', type=int, default=64)
     p.add_argument('--input_size', type=int, default=64)
     p.add_argument('--num_epochs', type=int, default=5)
@@ -39,15 +39,15 @@ def parse_arguments(argv=None):
     p.add_argument('--beta2', type=float, default=0.999)
     p.add_argument('--data_path', type=str, default='miniCelebA')
     p.add_argument("--wandb", default=None)
-    p.add_argument('--local_config', default=None, help='path to config file')
-    p.add_argument('--num_generated', type=int, default=2040, help='number of generated images, default=2040')
+    p.add_argument('--local_config', default=None, help='YAML file whose keys override these flags')
+    p.add_argument('--num_generated', type=int, default=2040, help='how many images the generate branch draws')
     p.add_argument("--PATH", type=str, default=os.path.join(os.getcwd(), 'ersecki-thesis', 'model_save', 'dcgan'))
     p.add_argument("--PATH_syn_data", type=str, default=os.path.join(os.getcwd(), 'ersecki-thesis', 'syn_data', 'dcgan'),
-                   help="Directory to save synthetic data")
+                   help="root folder of the npz_images / npz_noise / png_images outputs")
     p.add_argument("--save_model", type=bool, default=True)
-    p.add_argument("--saved_model_name", type=str, default=None, help="Saved model name")
+    p.add_argument("--saved_model_name", type=str, default=None, help="folder that holds generator.pth")
     p.add_argument("--training", type=bool, default=False, help="Training status (not available here)")
-    p.add_argument("--generate", type=bool, default=True, help="Generating Sythetic Data")
+    p.add_argument("--generate", type=bool, default=True, help="run the generate branch")
     p.add_argument('--ailab', type=bool, default=False)
     return p.parse_args(argv)
 

@@ -23,20 +23,20 @@ def parse_arguments(argv=None):
     p.add_argument('--batch_size', type=list, default=[16, 16, 16, 16, 16])
     p.add_argument('--image_size', type=int, default=64, help='the height / width of the generated images (the branch runs 4 steps: 64)')
     p.add_argument('--nc', type=int, default=3)
-    p.add_argument('--nz', type=int, default=256, help='size of the latent z vector')
-    p.add_argument('--in_channels', type=int, default=256, help='number of generator filters in first conv layer, default=256')
+    p.add_argument('--nz', type=int, default=256, help='length of a latent vector')
+    p.add_argument('--in_channels', type=int, default=256, help='channel count of the first block')
     p.add_argument('--start_img_size', type=int, default=4)
-    p.add_argument('--num_generated', type=int, default=10000, help='number of generated images')
+    p.add_argument('--num_generated', type=int, default=10000, help='how many images the generate branch draws')
     p.add_argument('--lambda_gp', type=float, default=10)
     p.add_argument('--data_path', type=str, default='miniCelebA')
-    p.add_argument('--local_config', default=None, help='path to config file')
+    p.add_argument('--local_config', default=None, help='YAML file whose keys override these flags')
     p.add_argument("--wandb", default=None)
     p.add_argument("--PATH", type=str, default=os.path.join(os.getcwd(), 'ersecki-thesis', 'model_save', 'dcgan'))
-    p.add_argument("--PATH_syn_data", type=str, default=os.path.join(os.getcwd(), 'ersecki-thesis', 'syn_data', 'dcgan'), help="Directory to save synthetic data")
+    p.add_argument("--PATH_syn_data", type=str, default=os.path.join(os.getcwd(), 'ersecki-thesis', 'syn_data', 'dcgan'), help="root folder of the npz_images / npz_noise / png_images outputs")
     p.add_argument("--save_model", type=bool, default=True)
-    p.add_argument("--saved_model_name", type=str, default=None, help="Saved model name")
+    p.add_argument("--saved_model_name", type=str, default=None, help="folder that holds generator.pth")
     p.add_argument("--training", type=bool, default=False, help="Training status (not available here)")
-    p.add_argument("--generate", type=bool, default=True, help="Generating Sythetic Data")
+    p.add_argument("--generate", type=bool, default=True, help="run the generate branch")
     p.add_argument('--ailab', type=bool, default=False)
     return p.parse_args(argv)
 

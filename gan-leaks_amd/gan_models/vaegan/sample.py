@@ -22,9 +22,9 @@ from .train import Generator
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser()
-    parser.add_argument('--model_dir', required=True, type=str, help='Directory for saving the model checkpoints')
-    parser.add_argument('--out_dir', type=str, help='path for saving the generated data (default: save to model dir)')
-    parser.add_argument('--num_samples', type=int, default=20000, help='num of samples')
+    parser.add_argument('--model_dir', required=True, type=str, help='folder that holds netG.pt (a state dict)')
+    parser.add_argument('--out_dir', type=str, help='where generated.npz and samples.png go (default: the model folder)')
+    parser.add_argument('--num_samples', type=int, default=20000, help='how many images to draw')
     return parser.parse_args(argv)
 
 

@@ -34,16 +34,16 @@ def parse_arguments(argv=None):
     p.add_argument('--beta2', type=float, default=0.9)
     p.add_argument('--dataroot', type=str, default=1)
     p.add_argument('--data_name', type=str, default='miniCelebA')
-    p.add_argument('--local_config', default=None, help='path to config file')
+    p.add_argument('--local_config', default=None, help='YAML file whose keys override these flags')
     p.add_argument("--wandb", default=None)
     p.add_argument("--PATH", type=str, default=os.path.join(os.getcwd(), 'model_save', 'wgangp'))
-    p.add_argument("--PATH_syn_data", type=str, default=os.path.join(os.getcwd(), 'syn_data', 'wgangp'), help="Directory to save synthetic data")
+    p.add_argument("--PATH_syn_data", type=str, default=os.path.join(os.getcwd(), 'syn_data', 'wgangp'), help="root folder of the npz_images / npz_noise / png_images outputs")
     p.add_argument("--save_model", type=bool, default=True)
-    p.add_argument("--saved_model_name", type=str, default=None, help="Saved model name")
+    p.add_argument("--saved_model_name", type=str, default=None, help="folder that holds generator.pth")
     p.add_argument("--training", type=bool, default=False, help="Training status (not available here)")
     p.add_argument("--resume", type=bool, default=False)
     p.add_argument("--finetuning", type=bool, default=False)
-    p.add_argument("--generate", type=bool, default=True, help="Generating Sythetic Data")
+    p.add_argument("--generate", type=bool, default=True, help="run the generate branch")
     p.add_argument("--evaluate", type=bool, default=False)
     return p.parse_args(argv)
 

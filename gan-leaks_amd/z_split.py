@@ -22,15 +22,15 @@ import numpy as np
 def parse_arguments(argv=None):
     """z_split.py:10-28 (same flags and defaults)"""
     p = argparse.ArgumentParser()
-    p.add_argument('--num_images', type=int, default=10020, help='the number of images to move to the two directories')
-    p.add_argument('--identity_annotations', type=str, default='data/identities_ann.txt', help='the path to the identity annotations file')
-    p.add_argument('--input_dir', type=str, default='data/img_align_celeba', help='the path to the input directory')
-    p.add_argument('--output_dir0', type=str, default='data/train', help='the path to the training-set output directory')
-    p.add_argument('--output_dir1', type=str, default='data/celebAhuge_positive', help='the path to the positive-query output directory')
-    p.add_argument('--output_dir2', type=str, default='data/celebAhuge_negative', help='the path to the negative-query output directory')
-    p.add_argument('--img_size', type=int, default=64, help='the height / width of the input image to network')
-    p.add_argument('--local_config', default=None, help='path to config file')
-    p.add_argument('--num_same_id', type=int, default=30, help='identity is considered if it has at least this number of images')
+    p.add_argument('--num_images', type=int, default=10020, help='images taken in total: a third become positive queries, a third negative ones')
+    p.add_argument('--identity_annotations', type=str, default='data/identities_ann.txt', help='text file with one `<identity> <image file>` pair per line')
+    p.add_argument('--input_dir', type=str, default='data/img_align_celeba', help='folder holding the aligned 218 x 178 CelebA pictures')
+    p.add_argument('--output_dir0', type=str, default='data/train', help='where the GAN training set (crop, random crop, mirrored crop) is written')
+    p.add_argument('--output_dir1', type=str, default='data/celebAhuge_positive', help='where the member (positive) query crops are written')
+    p.add_argument('--output_dir2', type=str, default='data/celebAhuge_negative', help='where the non-member (negative) query crops are written')
+    p.add_argument('--img_size', type=int, default=64, help='kept for compatibility; the crops are always 128 x 128')
+    p.add_argument('--local_config', default=None, help='YAML file whose keys override these flags')
+    p.add_argument('--num_same_id', type=int, default=30, help='an identity is private when it has exactly this many pictures, public when it has fewer')
     return p.parse_args(argv)
 
 
