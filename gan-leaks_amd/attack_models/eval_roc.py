@@ -62,21 +62,25 @@ def plot_roc(pos_results, neg_results):
     return fpr, tpr, threshold, auc, ap, precision
 
 
-def plot_hist(pos_dist, neg_dist, save_file):
-    """eval_roc.py:28-37: normalised histograms (100 bins) of the positive and negative distances"""
+def _pyplot():
     import matplotlib
     matplotlib.use('Agg')
-    import matplotlib.pyplot as plt
-    pos_dist, neg_dist = np.asarray(pos_dist).reshape(-1), np.asarray(neg_dist).reshape(-1)
-    plt.figure()
-    for d, label in ((pos_dist, 'positive'), (neg_dist, 'negative')):
-        plt.hist(d, bins=100, alpha=0.5, weights=np.full(d.shape, 1.0 / d.size), label=label)
-    plt.legend(loc='upper right')
-    plt.tight_layout()
-    plt.xlabel('distance')
-    plt.ylabel('normalized frequency')
-    plt.savefig(save_file)
-    plt.close()
+    from matplotlib import pyplot
+    return pyplot
+
+
+def plot_hist(pos_dist, neg_dist, save_file):
+    """eval_roc.py:28-37: normalised histograms (100 bins) of the positive and negative distances"""
+    plt = _pyplot()
+    fig, ax = plt.subplots()
+    for values, label in ((np.asarray(pos_dist).reshape(-1), 'positive'), (np.asarray(neg_dist).reshape(-1), 'negative')):
+        ax.hist(values, bins=100, alpha=0.5, weights=np.full(values.shape, 1.0 / values.size), label=label)
+    ax.legend(loc='upper right')
+    ax.set_xlabel('distance')
+    ax.set_ylabel('normalized frequency')
+    fig.tight_layout()
+    fig.savefig(save_file)
+    plt.close(fig)
 
 
 def parse_arguments(argv=None):
@@ -92,8 +96,8 @@ def parse_arguments(argv=None):
 
 
 def update_args(args, config_dict):
-    for key, val in config_dict.items():
-        setattr(args, key, val)
+    for name in config_dict:
+        setattr(args, name, config_dict[name])
 
 
 def main(args):
@@ -125,29 +129,26 @@ def main(args):
 
     if args.save_dir:
         try:
-            import matplotlib
-            matplotlib.use('Agg')
-            import matplotlib.pyplot as plt
-            plt.figure()
-            for f, t, label in curves:
-                plt.plot(f, t, label=label)
-            plt.legend(loc='lower right')
-            plt.xlabel('false positive')
-            plt.ylabel('true positive')
-            plt.title('ROC curve')
-            plt.savefig(os.path.join(result_load_dir, 'roc.png'))
-            plt.close()
+            plt = _pyplot()
         except ImportError:
             warnings.warn("matplotlib not available: roc.png not written")
+        else:
+            fig, ax = plt.subplots()
+            for f, t, label in curves:
+                ax.plot(f, t, label=label)
+            ax.legend(loc='lower right')
+            ax.set(xlabel='false positive', ylabel='true positive', title='ROC curve')
+            fig.savefig(os.path.join(result_load_dir, 'roc.png'))
+            plt.close(fig)
     return auc, ap, precision
 
 
 if __name__ == '__main__':
     import yaml
-    args = parse_arguments()
-    if args.local_config is not None:
-        with open(str(args.local_config), "r") as f:
-            update_args(args, yaml.safe_load(f))
-    else:
+    cli = parse_arguments()
+    if cli.local_config is None:
         warnings.warn("No config file was provided. Using default parameters.")
-    main(args)
+    else:
+        with open(str(cli.local_config)) as handle:
+            update_args(cli, yaml.safe_load(handle))
+    main(cli)

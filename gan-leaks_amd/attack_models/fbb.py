@@ -21,44 +21,58 @@ from ..attack import Bank, _budget_bytes, attack  # noqa: F401  (re-export)
 from .utils import (Loss, check_folder, get_filepaths_from_dir, read_images_u8_nchw, save_files)
 
 
+# (flag names, argparse keywords): the reference's command line (attack_models/fbb.py:18-38) plus --distance
+_FLAGS = (
+    (('--exp_name', '-name'), dict(type=str, default='debug', help='experiment name; results go to ./fbb_attack/<exp_name>')),
+    (('--syn_data_path',), dict(type=str, help='folder with the generated sample bank (image_*.png), or with one sub-folder per bank for a sweep')),
+    (('--pos_data_dir',), dict(type=str, default=None, help='folder with the member (training) query images')),
+    (('--neg_data_dir',), dict(type=str, default=None, help='folder with the non-member (held-out) query images')),
+    (('--data_num', '-dnum'), dict(type=int, default=20000, help='number of query images (kept for compatibility)')),
+    (('--resolution', '-resolution'), dict(type=int, default=64, help='images that differ are resized to this square size')),
+    (('--K',), dict(type=int, default=5)),
+    (('--BATCH_SIZE',), dict(type=int, default=30)),
+    (('--local_config',), dict(type=str, default=None)),
+    (('--hyperparameter_search',), dict(default=False, help='treat every sub-folder of syn_data_path as one bank')),
+    (('--params',), dict(type=str, default=None, help='name of the hyper-parameter setting (set per sub-folder in a sweep)')),
+    (('--wandb',), dict(default=None, help='accepted for compatibility; nothing is logged to WandB')),
+    (('--distance',), dict(type=str, default='l2-lpips', choices=['l2', 'l2-lpips'],
+                           help="[build] distance operator; the reference always uses 'l2-lpips' (fbb.py:148)")),
+)
+
+
 def parse_arguments(argv=None):
     """attack_models/fbb.py:18-38: identical flags and defaults, plus --distance."""
     parser = argparse.ArgumentParser()
-    parser.add_argument('--exp_name', '-name', type=str, default='debug',
-                        help='the name of the current experiment (used to set up the save_dir)')
-    parser.add_argument('--syn_data_path', type=str, help='directory to the synthetic data')
-    parser.add_argument('--pos_data_dir', type=str, default=os.path.join(os.getcwd(), 'data', 'miniCelebA', 'train'),
-                        help='the directory for the positive (training) query images set')
-    parser.add_argument('--neg_data_dir', type=str, default=os.path.join(os.getcwd(), 'data', 'miniCelebA', 'test'),
-                        help='the directory for the negative (testing) query images set')
-    parser.add_argument('--data_num', '-dnum', type=int, default=20000, help='the number of query images to be considered')
-    parser.add_argument('--resolution', '-resolution', type=int, default=64, help='generated image resolution')
-    parser.add_argument('--K', type=int, default=5)
-    parser.add_argument('--BATCH_SIZE', type=int, default=30)
-    parser.add_argument('--local_config', type=str, default=None)
-    parser.add_argument('--hyperparameter_search', default=False, help='tune hyperparameters')
-    parser.add_argument('--params', type=str, default=None, help='hyperparameters to tune')
-    parser.add_argument("--wandb", default=None, help="accepted for compatibility; logging to WandB is not performed")
-    parser.add_argument('--distance', type=str, default='l2-lpips', choices=['l2', 'l2-lpips'],
-                        help="[build] distance operator; the reference always uses 'l2-lpips' (fbb.py:148)")
+    data_root = os.path.join(os.getcwd(), 'data', 'miniCelebA')
+    for names, kw in _FLAGS:
+        kw = dict(kw)
+        if names[0] == '--pos_data_dir':
+            kw['default'] = os.path.join(data_root, 'train')
+        elif names[0] == '--neg_data_dir':
+            kw['default'] = os.path.join(data_root, 'test')
+        parser.add_argument(*names, **kw)
     return parser.parse_args(argv)
 
 
 def check_args(args):
-    """attack_models/fbb.py:42-67: save_dir = ./fbb_attack/<exp_name>[/<params>], params.txt + params.pkl"""
+    """attack_models/fbb.py:42-67: the bank folder must exist; results go to ./fbb_attack/<exp_name> -- in a sweep to
+    ./fbb_attack/<exp_name>__<sweep folder>/<params> -- and the arguments are recorded there as params.txt ("key:value" lines, also
+    echoed) and params.pkl (pickle protocol 2 of the same dict)."""
     assert os.path.exists(args.syn_data_path)
-    if args.params is not None and args.hyperparameter_search:
-        subdir = args.syn_data_path
-        exp_name = args.exp_name + '__' + subdir.split('/')[-2]
-        save_dir = os.path.join(os.getcwd(), 'fbb_attack', exp_name, args.params)
+    root = os.path.join(os.getcwd(), 'fbb_attack')
+    if args.hyperparameter_search and args.params is not None:
+        sweep_folder = args.syn_data_path.split('/')[-2]
+        save_dir = os.path.join(root, '%s__%s' % (args.exp_name, sweep_folder), args.params)
     else:
-        save_dir = os.path.join(os.getcwd(), 'fbb_attack', args.exp_name)
+        save_dir = os.path.join(root, args.exp_name)
     check_folder(save_dir)
-    with open(os.path.join(save_dir, 'params.txt'), 'w') as f:
-        for k, v in vars(args).items():
-            f.writelines(k + ":" + str(v) + "\n")
-            print(k + ":" + str(v))
-    pickle.dump(vars(args), open(os.path.join(save_dir, 'params.pkl'), 'wb'), protocol=2)
+    record = vars(args)
+    lines = ["%s:%s" % (key, value) for key, value in record.items()]
+    with open(os.path.join(save_dir, 'params.txt'), 'w') as handle:
+        handle.write("".join(line + "\n" for line in lines))
+    print("\n".join(lines))
+    with open(os.path.join(save_dir, 'params.pkl'), 'wb') as handle:
+        pickle.dump(record, handle, protocol=2)
     return args, save_dir
 
 
@@ -195,17 +209,17 @@ def main(args):
 
 
 def update_args(args, config_dict):
-    """attack_models/fbb.py:182-184"""
-    for key, val in config_dict.items():
-        setattr(args, key, val)
+    """attack_models/fbb.py:182-184: keys of the YAML config override the command line"""
+    for name in config_dict:
+        setattr(args, name, config_dict[name])
 
 
 if __name__ == '__main__':
     import yaml
-    args = parse_arguments()
-    if args.local_config is not None:
-        with open(str(args.local_config), "r") as f:
-            update_args(args, yaml.safe_load(f))
-    else:
+    cli = parse_arguments()
+    if cli.local_config is None:
         warnings.warn("No config file was provided. Using default parameters.")
-    main(args)
+    else:
+        with open(str(cli.local_config)) as handle:
+            update_args(cli, yaml.safe_load(handle))
+    main(cli)
