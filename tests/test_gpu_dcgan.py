@@ -213,3 +213,21 @@ def test_fused_tail_matches_separate_launches(gl, synth, oracle):
         assert np.abs(fused - separate).max() < 2e-6
         ref = oracle.dcgan_generator_forward(sd, z[:3])
         assert np.abs(fused[:3] - ref).max() < tol and np.abs(separate[:3] - ref).max() < tol
+
+
+@pytest.mark.parametrize("gain", [0.05, 1.0, 4.0])
+def test_split_arithmetic_is_fp32_class_for_any_weight_scale(gain, gl, synth, oracle):
+    """the split-fp16 path is never less accurate than the fp32-MFMA path against the fp64 oracle, from tiny weights (outputs ~0.1) to
+    weights that saturate tanh and amplify rounding (fp32 itself 3e-4 off at gain 4)"""
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(2, gain=gain)
+    z = synth.latent(12, 32)
+    ref = oracle.dcgan_generator_forward(sd, z[:4])
+    err = {}
+    for mode in (1, 0):
+        g = Generator(100, 3, 64)
+        g.load_state_dict(sd)
+        g.set_precision(mode)
+        err[mode] = np.abs(g.forward_device(z, True, False)[0].numpy()[:4] - ref).max()
+        assert g._precision == mode
+    assert err[1] <= 1.5 * err[0] + 1e-7, err
