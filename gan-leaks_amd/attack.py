@@ -263,11 +263,12 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
         fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=model.search_role("query"))
         b_role = "bank" if getattr(fq, "role", None) else None
         step = max(1, int(chunk_bytes // (fq.K * (2 if fq.role else 4))))
-        keys = None
+        keys, buf = None, None
         for lo in range(0, n_rows, step):
             hi = min(lo + step, n_rows)
-            keys = _lp.feat_knn_keys(model.features(rows(lo, hi), index_base=base + lo, role=b_role), fq, keys=keys)
-            ctx.sync()                   # the chunk's rows are released when the temporaries go
+            buf = model.features(rows(lo, hi), index_base=base + lo, role=b_role, out=buf)     # one feature buffer, reused by every chunk
+            keys = _lp.feat_knn_keys(buf, fq, keys=keys)
+            ctx.sync()
         return finish(keys, fq.n, fq.K, "f32")
 
     # 'l2': every chunk must take the same arithmetic path.  Exact integers unless the queries or some chunk are off the 8-bit lattice;

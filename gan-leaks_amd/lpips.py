@@ -114,8 +114,9 @@ class LpipsModel:
             raise ValueError("LpipsModel.search_rows must be 'fp16' or 'split', got %r" % (self.search_rows,))
         return role if self.search_rows == "fp16" else None
 
-    def features(self, images, index_base=0, role=None):
-        """images [n,3,H,W] (u8, or float in [-1,1]) -> FeatureBank.  role None: split rows; 'query' / 'bank': search rows."""
+    def features(self, images, index_base=0, role=None, out=None):
+        """images [n,3,H,W] (u8, or float in [-1,1]) -> FeatureBank.  role None: split rows; 'query' / 'bank': search rows.
+        out: a FeatureBank of the same role and image size with at least n rows whose buffers are overwritten (streamed banks reuse one)."""
         if role not in (None, "query", "bank"):
             raise ValueError("role must be None, 'query' or 'bank', got %r" % (role,))
         if not self._loaded:
@@ -129,12 +130,17 @@ class LpipsModel:
         if K < 0:
             raise ValueError("LPIPS path needs H and W to be multiples of 16, got %dx%d" % (H, W))
         rows = _to_device_rows(ctx, images)
-        if role is None:
+        K1 = int(ctx.lib.gl_lpips_search_dim(H, W)) if role is not None else K
+        if out is not None:
+            if getattr(out, "role", None) != role or out.K != K1 or out.V.shape[0] < n:
+                raise ValueError("features(out=...): buffer of another role / image size, or too small")
+            V, norms = out.V, out.norms
+        elif role is None:
             V = ctx.empty((max(n, 1), K), np.float32)
+            norms = ctx.empty((max(n, 1),), np.float32)
         else:
-            K1 = int(ctx.lib.gl_lpips_search_dim(H, W))
             V = ctx.empty((max(n, 1), K1), np.float16)
-        norms = ctx.empty((max(n, 1),), np.float32)
+            norms = ctx.empty((max(n, 1),), np.float32)
         r = 0 if role == "query" else 1
         if rows.dtype == np.float32:
             u8, bad = encode_if_lattice(ctx, rows)
