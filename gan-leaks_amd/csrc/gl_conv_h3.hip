@@ -10,10 +10,11 @@
 // order of gl_conv_k_index.  The gather addressing (buffer_load ... lds with scalar per-slice offsets and hardware
 // zero-fill for padding) is therefore byte-identical to gather_conv_kernel's.
 //
-// Tiling: 128 output channels x 128 positions per workgroup, 4 waves as 2 x 2, each 64 x 64 = 4 x 4 tiles of 16 x 16
-// (weights are the MFMA A operand, positions the B operand, so a lane ends up with 4 consecutive channels of one
-// position: one 8-byte store for the hi halves, one for the lo halves).  LDS rows are 128 B, chunk c of row r at slot
-// c ^ (r & 7): conflict-free ds_read_b128 (same scheme as l2_knn_i8_kernel).
+// Tiling: WC x WP waves per workgroup, each TC x TP tiles of 16 x 16 (shapes below).  Weights are the MFMA A operand, positions the
+// B operand, so a lane ends up with 4 consecutive channels of one position: one 8-byte store for the hi halves, one for the lo
+// halves.  LDS rows are 128 B, chunk c of row r at slot c ^ (r & 7): conflict-free ds_read_b128 (same scheme as l2_knn_i8_kernel).
+// FUSE_TAIL: the next layer -- a per-position GEMM with 48 columns over this layer's 64 or 128 channels, i.e. the generator's
+// ConvTranspose2d(C -> 3, k4 s2 p1) in scatter form -- is evaluated in the epilogue on the activations still in registers.
 #include "gl_conv.h"
 #include <cstdlib>
 #include <type_traits>
@@ -32,8 +33,8 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 //   <2,4,8,4>: 256 channels x 256 positions, 8 waves of 128 x 64, 128 KiB LDS (1 workgroup per CU): wide layers of large passes
 // K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): a 128 x 256
 // tile with 8 waves of 64 x 64, 256 x 256 with 4 waves of 128 x 128 (1 wave per SIMD), 128 x 512 / 128 x 256 tiles for 128-column
-// layers, a ring of three slices with counted
-// s_waitcnt vmcnt(N), 4 workgroups per CU.
+// layers, a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU, staggered staging of the two wave halves,
+// halo staging (one staged pixel range per channel chunk, taps as shifted rows).
 template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
