@@ -182,7 +182,7 @@ struct gl_pggan {
     int precision;
     struct H3 { float *w, *scale, *shift; } h_init, h_i3, h_blk[kBlocks][2], h_rgb[kBlocks + 1];
     int64_t chunk, ws_imgs;
-    size_t ws_act_elems, ws_rgb_elems;
+    size_t ws_act_elems, ws_rgb_elems;      // floats allocated per activation / rgb buffer
     float *ws_z, *ws_buf[3], *ws_rgb[2];
 };
 
@@ -413,28 +413,30 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
     if (want < 1) want = 1;
     if (want > n) want = n;
     const size_t rgb_elems = (size_t)R * R * 4;      // up to 4 floats per pixel (split path pads 3 -> 4)
-    if (want > g->ws_imgs || act > g->ws_act_elems || rgb_elems > g->ws_rgb_elems) {
+    // `want` images per pass for THIS depth; the buffers only ever grow (ws_imgs latent rows, ws_act_elems / ws_rgb_elems floats per buffer)
+    const size_t need_act = (size_t)want * act, need_rgb = (size_t)want * rgb_elems;
+    if (want > g->ws_imgs || need_act > g->ws_act_elems || need_rgb > g->ws_rgb_elems) {
         GL_HIP(hipStreamSynchronize(ctx->stream));
-        if (want < g->ws_imgs) want = g->ws_imgs;
-        if (act < g->ws_act_elems) act = g->ws_act_elems;
-        const size_t rgb_alloc = rgb_elems > g->ws_rgb_elems ? rgb_elems : g->ws_rgb_elems;
+        const int64_t z_rows = want > g->ws_imgs ? want : g->ws_imgs;
+        const size_t act_alloc = need_act > g->ws_act_elems ? need_act : g->ws_act_elems;
+        const size_t rgb_alloc = need_rgb > g->ws_rgb_elems ? need_rgb : g->ws_rgb_elems;
         (void)hipFree(g->ws_z);
         for (int k = 0; k < 3; ++k) { (void)hipFree(g->ws_buf[k]); g->ws_buf[k] = nullptr; }
         for (int k = 0; k < 2; ++k) { (void)hipFree(g->ws_rgb[k]); g->ws_rgb[k] = nullptr; }
         g->ws_z = nullptr;
-        g->ws_imgs = 0;
-        GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
-        for (int k = 0; k < 3; ++k) GL_HIP(hipMalloc((void **)&g->ws_buf[k], (size_t)want * act * 4));
-        for (int k = 0; k < 2; ++k) GL_HIP(hipMalloc((void **)&g->ws_rgb[k], (size_t)want * rgb_alloc * 4 + 64));
-        g->ws_imgs = want;
-        g->ws_act_elems = act;
+        g->ws_imgs = 0; g->ws_act_elems = 0; g->ws_rgb_elems = 0;
+        GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)z_rows * g->z_pad * 4));
+        for (int k = 0; k < 3; ++k) GL_HIP(hipMalloc((void **)&g->ws_buf[k], act_alloc * 4));
+        for (int k = 0; k < 2; ++k) GL_HIP(hipMalloc((void **)&g->ws_rgb[k], rgb_alloc * 4 + 64));
+        g->ws_imgs = z_rows;
+        g->ws_act_elems = act_alloc;
         g->ws_rgb_elems = rgb_alloc;
     }
     const int64_t img_elems = (int64_t)nc * R * R;
     int rc;
 
-    for (int64_t i0 = 0; i0 < n; i0 += g->ws_imgs) {
-        const int64_t m = (n - i0 < g->ws_imgs) ? n - i0 : g->ws_imgs;
+    for (int64_t i0 = 0; i0 < n; i0 += want) {
+        const int64_t m = (n - i0 < want) ? n - i0 : want;
         const bool h3 = g->precision == 1;
         if (h3)
             hipLaunchKernelGGL(pixelnorm_rows_split_kernel, dim3((unsigned)gl_ceil_div(m, 4)), dim3(256), 0, ctx->stream, z_dev + i0 * g->z_dim, m, g->z_dim,

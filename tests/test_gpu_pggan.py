@@ -86,3 +86,20 @@ def test_pggan_bank_attack(gl, synth):
     d, i = gl.attack(q, bank, batch_size=64)
     od, oi, _ = c_oracle.knn_l2_u8(hb, q, 64)
     assert np.array_equal(i, oi) and np.array_equal(d, od) and i[0] == 7 and i[1] == 150 and i[2] != 199
+
+
+def test_depth_changes_on_one_object(gl, synth):
+    """steps=4 then steps=6 then steps=4 on the same generator: the workspace is re-sized per depth (a pass of the shallow depth
+    must not be reused as the pass size of the deep one: its largest activation would exceed the 3 GiB addressing limit)"""
+    from ganleaks_amd.gan_models.pggan.model_torch import Generator
+    sd = synth.pggan_state_dict(11, 64, 256)
+    g = Generator(64, 256, 3)
+    g.load_state_dict(sd)
+    z = synth.latent(12, 300, 64)
+    a4 = g.forward_device(z, 4, 1.0, True, False)[0].numpy()
+    a6 = g.forward_device(z[:70], 6, 1.0, True, False)[0].numpy()
+    b4 = g.forward_device(z, 4, 1.0, True, False)[0].numpy()
+    assert a6.shape == (70, 3, 256, 256) and np.array_equal(a4, b4)
+    fresh = Generator(64, 256, 3)
+    fresh.load_state_dict(sd)
+    assert np.array_equal(fresh.forward_device(z[:70], 6, 1.0, True, False)[0].numpy(), a6)

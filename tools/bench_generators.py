@@ -46,6 +46,11 @@ def main():
         g.set_precision(mode)
         t = timed(lambda: g.forward_device(z, 4, 1.0, False, True))
         out.append({"generator": "PGGAN-64 (in_channels 512, steps 4)", "precision": mode, "images": n, "images_per_s": n / t, "alg_tflops": n * 27.3e9 / t / 1e12})
+    n = 512
+    z = ctx.to_device(synth.latent(2, n, 512).reshape(n, 512))
+    g.set_precision(1)
+    t = timed(lambda: g.forward_device(z, 6, 1.0, False, True))
+    out.append({"generator": "PGGAN-256 (in_channels 512, steps 6)", "precision": 1, "images": n, "images_per_s": n / t, "alg_tflops": n * 56.3e9 / t / 1e12})
     n = 16384
     g = VAEGAN(100, 64)
     g.load_state_dict(synth.vaegan_state_dict(777, 100, 64))
