@@ -340,3 +340,24 @@ def test_codec_kernels(gl, synth, oracle, coracle):
     assert lib.gl_l2_prepare(ctx.handle, p(du.ptr), len(u), d, p(rows.ptr), p(norms.ptr)) == 0
     assert np.array_equal(norms.numpy(), coracle.row_norms_u8(u))
     assert np.array_equal(rows.numpy()[:, :d].astype(np.int16) + 128, u.reshape(len(u), -1).astype(np.int16))
+
+
+def test_randomised_shapes_vs_c_oracle(gl, coracle):
+    """40 seeded random problem shapes (odd row lengths, single rows, batch sizes that do not divide the bank, chunked and resident) against
+    the C oracle: indices and distances bit for bit"""
+    rng = np.random.default_rng(20240)
+    for case in range(40):
+        d = int(rng.choice([1, 3, 7, 48, 100, 127, 128, 129, 300, 768, 1071, 3072, 5000]))
+        nb = int(rng.integers(1, 700))
+        nq = int(rng.integers(1, 300))
+        bs = int(rng.choice([1, 2, 7, 30, 64]))
+        if nb < bs:
+            nb = bs
+        lo, hi = (0, 256) if case % 3 else (100, 140)                 # narrow ranges produce many exact ties
+        bank = rng.integers(lo, hi, size=(nb, d), dtype=np.uint8)
+        q = rng.integers(lo, hi, size=(nq, d), dtype=np.uint8)
+        q[0] = bank[int(rng.integers(0, nb))]
+        od, oi, _ = coracle.knn_l2_u8(bank, q, bs)
+        kw = {"chunk_bytes": int(rng.integers(1, 40)) * 2 * d} if case % 4 == 0 else {}
+        dist, idx = gl.attack(q, bank, batch_size=bs, **kw)
+        assert np.array_equal(idx, oi) and np.array_equal(dist, od), (case, d, nb, nq, bs)
