@@ -233,3 +233,23 @@ def test_fbb_main_default_distance_with_local_weights(tmp_path, monkeypatch, gl,
     assert np.array_equal(np.load(out / "pos_nn_idx.npy")[:, 0], i_ref)
     assert np.allclose(np.load(out / "pos_loss.npy")[:, 0], d_ref.astype(np.float64), atol=1e-7)
     lpips.set_default_model(None)
+
+
+@pytest.mark.parametrize("hw", [(32, 48), (48, 16), (16, 16)])
+def test_non_square_images(hw, gl, synth, model, lin, oracle):
+    """H != W and the smallest supported size (four 2x2 pools need multiples of 16) against the fp64 oracle, both row formats"""
+    import lpips_oracle
+    H, W = hw
+    rng = np.random.default_rng(H * 100 + W)
+    bank = rng.integers(0, 256, (24, 3, H, W), dtype=np.uint8)
+    q = np.clip(bank[[3, 17]].astype(int) + rng.integers(-9, 10, (2, 3, H, W)), 0, 255).astype(np.uint8)
+    od, oi, _ = lpips_oracle.knn_l2_lpips(synth.vgg16_state_dict(7), [lin["lin%d" % i] for i in range(5)], oracle.dequantize_u8(bank), oracle.dequantize_u8(q), 8)
+    for rows in ("fp16", "split"):
+        model.search_rows = rows
+        try:
+            d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=8, lpips=model)
+        finally:
+            model.search_rows = "fp16"
+        assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
+    with pytest.raises(ValueError):
+        gl.attack(q[:, :, :, :8], bank[:, :, :, :8], distance="l2-lpips", batch_size=8, lpips=model)
