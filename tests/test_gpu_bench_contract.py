@@ -1,0 +1,40 @@
+"""The driver's contract with bench.py: one JSON line on stdout with the agreed fields, also at reduced sizes and for both distances."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), check=True, stdout=subprocess.PIPE, cwd=ROOT).stdout.decode()
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    return json.loads(lines[0])
+
+
+def test_bench_line_fields():
+    d = _run("--steps", "2", "--warmup", "1", "--queries", "512", "--bank", "4096", "--cpu-queries", "8", "--cpu-seconds", "5")
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(d[key], typ), (key, d[key])
+    assert d["vs_baseline"] is None and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 512 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert d["parity"]["idx_equal"] is True and d["parity"]["max_abs_dist_err"] == 0.0
+
+
+def test_bench_line_l2_lpips():
+    d = _run("--distance", "l2-lpips", "--steps", "1", "--warmup", "1", "--queries", "256", "--bank", "1024", "--cpu-queries", "0")
+    assert d["roofline"]["bound"] == "mfma" and d["cpu_baseline"] is None and d["parity"]["idx_equal"] is True
+    assert d["parity"]["max_abs_dist_err"] < 1e-5
