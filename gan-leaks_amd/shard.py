@@ -74,3 +74,56 @@ def allreduce_min_keys_host(keys_host, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return t.numpy().view(np.uint64)
+
+
+def attack_on_devices(queries, make_generator, z, devices=None, distance="l2", batch_size=64, make_lpips=None, weights=None, **generate_kwargs):
+    """The sharded attack inside ONE process: a host thread per GPU, each with its own context, generates and searches its range of the
+    latents; the packed keys are min-merged on the host (Q x 8 bytes per device) -- no launcher and no RCCL.  The alternative to
+    `torch.distributed` + `allreduce_min_keys` for callers that do not want one process per GPU.
+
+    make_generator(ctx) -> a generator bound to that context with its weights loaded (e.g. dcgan.Generator(100, 3, 64, ctx) + load_state_dict)
+    make_lpips(ctx)     -> an LpipsModel for 'l2-lpips'
+    devices             -> list of device ordinals (default: all visible); weights -> relative speeds for `weighted_bounds`
+    returns (dist float32 [Q], idx int64 [Q]), identical to the single-device result."""
+    import threading
+    from ._lib import Context, device_count
+    from .attack import GeneratedBank, attack
+    devices = list(range(device_count())) if devices is None else list(devices)
+    if not devices:
+        raise ValueError("no devices")
+    world = len(devices)
+    n_eff = (len(z) // int(batch_size)) * int(batch_size)
+    if n_eff == 0:
+        raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
+    bounds = weighted_bounds(n_eff, weights, int(batch_size)) if weights is not None else [n_eff * r // world for r in range(world + 1)]
+    barrier = threading.Barrier(world)
+    deposits, results, errors = [None] * world, [None] * world, []
+
+    def reduce_fn_for(rank, ctx):
+        def reduce_fn(keys):
+            deposits[rank] = keys.numpy()
+            barrier.wait()
+            return ctx.to_device(merge_keys_host(deposits))
+        return reduce_fn
+
+    def work(rank):
+        try:
+            ctx = Context(devices[rank])
+            gen = make_generator(ctx)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            bank = GeneratedBank(gen, z[lo:hi], index_base=lo, **generate_kwargs)
+            model = make_lpips(ctx) if (distance == "l2-lpips" and make_lpips is not None) else None
+            results[rank] = attack(queries, bank, distance=distance, batch_size=batch_size, ctx=ctx, reduce_fn=reduce_fn_for(rank, ctx), lpips=model)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(e)
+            barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return results[0]
+

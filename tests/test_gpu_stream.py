@@ -82,3 +82,27 @@ def test_l2_lpips_streamed_equals_resident(gl, synth, golden_dir):
         d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=model, chunk_bytes=5 * row_bytes)
         assert np.array_equal(i, i0) and np.array_equal(d, d0)
     model.search_rows = "fp16"
+
+
+def test_attack_on_devices_in_one_process(gl, synth):
+    """shard.attack_on_devices: a host thread and a context per device, keys merged on the host.  One GPU here, so the 'devices' are
+    [0, 0, 0]: three contexts (three streams) on the same device; the result must equal the single-context one bit for bit."""
+    from ganleaks_amd import shard
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(1234, features_g=16)
+
+    def make(ctx):
+        g = Generator(100, 3, 16, ctx)
+        g.load_state_dict(sd)
+        return g
+
+    z = synth.latent(1, 500)
+    g0 = make(gl.Context.get())
+    q = synth.perturb_u8(5, g0.generate_u8(synth.latent(2, 40)).numpy(), 6.0)
+    d0, i0 = gl.attack(q, g0.generate_u8(z), distance="l2", batch_size=64)
+    d, i = shard.attack_on_devices(q, make, z, devices=[0, 0, 0], distance="l2", batch_size=64)
+    assert np.array_equal(i, i0) and np.array_equal(d, d0) and i.max() < 448
+    d, i = shard.attack_on_devices(q, make, z, devices=[0, 0], batch_size=64, weights=[1.0, 3.0])
+    assert np.array_equal(i, i0) and np.array_equal(d, d0)
+    with pytest.raises(ValueError):
+        shard.attack_on_devices(q, make, z[:10], devices=[0], batch_size=64)
