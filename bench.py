@@ -300,8 +300,10 @@ def main():
     kernels = [k for k in kernels if k and k["alg_per_launch"] > 0]
     # HBM-side traffic per launch from the PMC counters: cannot be collected from inside this process; taken from the committed
     # rocprofv3 --pmc passes of this exact workload (profiles/r01/pmc_traffic_default.json says how), null for any other workload
-    traffic_file = os.path.join(ROOT, "profiles", "r01", "pmc_traffic_default.json")
-    if os.path.exists(traffic_file) and world == 1 and Q == 10000 and N == 100000 and lp_model is None and split:
+    import glob
+    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_default.json")))     # the latest round's passes
+    traffic_file = traffic_files[-1] if traffic_files else ""
+    if traffic_file and world == 1 and Q == 10000 and N == 100000 and lp_model is None and split:
         with open(traffic_file) as f:
             tr = json.load(f)
         for k in kernels:

@@ -28,4 +28,4 @@ cp "$OUT/generators.jsonl" "profiles/$TAG/${TAG}_generators.jsonl"
 cp "$OUT/auroc_delta_full_config2.json" "profiles/$TAG/${TAG}_auroc_delta_full_config2.json"
 python3 tools/pmc_summary.py "profiles/$TAG/pmc_traffic_default.json" "$OUT/pmc_fetch" "$OUT/pmc_write" > /dev/null
 python3 tools/pmc_summary.py "profiles/$TAG/${TAG}_pmc_sq_default.json" "$OUT/pmc_sq" > /dev/null
-echo "profiles/$TAG refreshed (bench.py reads profiles/r01/pmc_traffic_default.json for roofline.traffic: update the path there when the tag changes)"
+echo "profiles/$TAG refreshed (bench.py takes roofline.traffic from the newest profiles/r*/pmc_traffic_default.json)"
