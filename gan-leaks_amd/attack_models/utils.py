@@ -92,6 +92,58 @@ def read_images_u8_nchw(paths, resolution=64, workers=None):
         return np.array(np.memmap(out_file, np.uint8, "r", shape=(n, 3, resolution, resolution)))
 
 
+NCOLS = 5          # images per row in the figure helpers below (attack_models/utils.py:16)
+
+
+def inverse_transform(imgs):
+    """[-1, 1] images -> [0, 1]  (attack_models/utils.py:90-98)"""
+    return (imgs + 1.) / 2.
+
+
+def _image_grid(imgs, titles, path, figure):
+    """NCOLS images per row, axes off, optional title per image; the figure helpers of attack_models/utils.py:101-138 (used by the
+    white-box / partial-black-box attacks' progress dumps, not by fbb) share this body"""
+    import matplotlib
+    matplotlib.use('Agg')
+    from matplotlib import pyplot
+    shown = np.clip(inverse_transform(np.asarray(imgs)), 0., 1.)
+    rows = int(np.ceil(len(shown) / float(NCOLS)))
+    fig = pyplot.figure(figure)
+    for k, picture in enumerate(shown):
+        ax = fig.add_subplot(rows, NCOLS, k + 1)
+        ax.imshow(picture)
+        if titles is not None:
+            ax.set_title(titles[k], fontdict={'fontsize': 8, 'color': 'blue'})
+        ax.axis('off')
+    fig.savefig(path)
+    pyplot.close(fig)
+
+
+def visualize_gt(imgs, save_dir):
+    """HWC images in [-1, 1] -> <save_dir>/input.png  (attack_models/utils.py:101-116)"""
+    _image_grid(imgs, None, os.path.join(save_dir, 'input.png'), 1)
+
+
+def visualize_progress(imgs, loss, save_dir, counter):
+    """the same with 'loss: %.4f' titles -> <save_dir>/output_<counter>.png  (attack_models/utils.py:119-138)"""
+    _image_grid(imgs, ['loss: %.4f' % v for v in loss], os.path.join(save_dir, 'output_%d.png' % counter), 2)
+
+
+def visualize_samples(img_r01, save_dir):
+    """the first 64 HWC images in [0, 1] as an 8 x 8 sheet -> <save_dir>/samples.png  (attack_models/utils.py:141-148)"""
+    import matplotlib
+    matplotlib.use('Agg')
+    from matplotlib import pyplot
+    fig = pyplot.figure(figsize=(20, 20))
+    for k in range(64):
+        ax = fig.add_subplot(8, 8, k + 1)
+        ax.imshow(img_r01[k])
+        ax.axis('off')
+    fig.tight_layout()
+    fig.savefig(os.path.join(save_dir, 'samples.png'))
+    pyplot.close(fig)
+
+
 class Loss:
     """attack_models/utils.py:153-177.  Loss(distance, if_norm_reg=False); forward(x_hat, x_gt) -> [B].
 

@@ -83,6 +83,19 @@ def test_plot_hist_writes_a_figure(gl, tmp_path):
     assert out.stat().st_size > 1000
 
 
+def test_figure_helpers(gl, tmp_path):
+    pytest.importorskip("matplotlib")
+    from ganleaks_amd.attack_models import utils
+    rng = np.random.default_rng(1)
+    imgs = rng.uniform(-1, 1, (7, 16, 16, 3))
+    assert np.allclose(utils.inverse_transform(np.array([-1.0, 0.0, 1.0])), [0.0, 0.5, 1.0]) and utils.NCOLS == 5
+    utils.visualize_gt(imgs, str(tmp_path))
+    utils.visualize_progress(imgs, rng.uniform(0, 1, 7), str(tmp_path), 3)
+    utils.visualize_samples(rng.uniform(0, 1, (64, 8, 8, 3)), str(tmp_path))
+    for name in ("input.png", "output_3.png", "samples.png"):
+        assert (tmp_path / name).stat().st_size > 1000
+
+
 def test_fbb_cli_surface(gl):
     from ganleaks_amd.attack_models import fbb
     a = fbb.parse_arguments([])
