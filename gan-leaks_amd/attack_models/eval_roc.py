@@ -44,7 +44,8 @@ def plot_roc(pos_results, neg_results):
     fps_f = np.r_[0, fps].astype(np.float64)
     if tps_f[-1] <= 0 or fps_f[-1] <= 0:
         raise ValueError("Only one class present; ROC AUC is not defined")
-    auc = float(np.trapezoid(tps_f / tps_f[-1], fps_f / fps_f[-1]))
+    x_, y_ = fps_f / fps_f[-1], tps_f / tps_f[-1]
+    auc = float(np.sum(np.diff(x_) * (y_[1:] + y_[:-1])) * 0.5)      # trapezoid rule, written out (np.trapezoid needs numpy >= 2, the reference pins 1.24)
 
     # roc_curve(drop_intermediate=True): drop collinear points, then prepend (0, 0, inf)
     if len(fps) > 2:

@@ -201,7 +201,9 @@ class Loss:
         g = Bank.from_images(x_gt, ctx, keep_u8=True, force_kind="f32" if a.kind == "f32" else None)
         if a.d != g.d:
             raise ValueError("image sizes differ")
-        if a.kind != g.kind:
+        if a.kind != g.kind or a.kind == "int":
+            # mixed lattices, or whole-number rows (0/1 tables, raw 0..255 floats): x = float(u) has no 4/255^2 scale, so the per-row
+            # form runs on the fp32 kernel (its sums of small integers are exact, the result is fl32(S/d))
             a, g = a.as_f32(), g.as_f32()
         out = ctx.empty((max(a.n, 1),), np.float32)
         if a.kind == "u8":

@@ -232,9 +232,17 @@ int gl_encode_integers_f32(gl_ctx *ctx, const float *x_dev, int64_t count, uint8
     return encode_impl(ctx, x_dev, count, u8_dev, off_lattice_dev, true);
 }
 
-int gl_decode_u8(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev) { return decode_impl(ctx, u8_dev, count, x_dev, false); }
+int gl_decode_u8(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev)
+{
+    gl_make_current(ctx);
+    return decode_impl(ctx, u8_dev, count, x_dev, false);
+}
 
-int gl_decode_u8_integers(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev) { return decode_impl(ctx, u8_dev, count, x_dev, true); }
+int gl_decode_u8_integers(gl_ctx *ctx, const uint8_t *u8_dev, int64_t count, float *x_dev)
+{
+    gl_make_current(ctx);
+    return decode_impl(ctx, u8_dev, count, x_dev, true);
+}
 
 int gl_quantize_f32(gl_ctx *ctx, const float *x_dev, int64_t count, int mode, uint8_t *u8_dev)
 {

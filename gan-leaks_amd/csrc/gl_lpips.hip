@@ -1166,6 +1166,20 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
     uint64_t *keys = nullptr;
     int64_t *idx = nullptr;
     int rc = GL_OK;
+    const int precision_in = l->precision;
+    // split-fp16 VGG16 stores clamp at the fp16 range and count it: a chunk whose features saturated is recomputed with fp32 products (and so is
+    // everything after it), as LpipsModel.features does on the Python side
+    auto features = [&](int64_t n, int role, void *V, float *norms) -> int {
+        int64_t sat = 0;
+        int r = gl_ctx_h3_saturations(ctx, &sat);                      // clear what earlier calls on this context left behind
+        if (r != GL_OK) return r;
+        r = gl_lpips_search_features_u8(l, raw, n, H, W, role, V, norms);
+        if (r != GL_OK || l->precision == 0) return r;
+        r = gl_ctx_h3_saturations(ctx, &sat);
+        if (r != GL_OK || sat == 0) return r;
+        l->precision = 0;
+        return gl_lpips_search_features_u8(l, raw, n, H, W, role, V, norms);
+    };
 #define GL_TRY(e) do { rc = (e); if (rc != GL_OK) goto done; } while (0)
     GL_TRY(gl_malloc(ctx, (size_t)((chunk > nq ? chunk : nq) * D), (void **)&raw));
     GL_TRY(gl_malloc(ctx, (size_t)(nq * row), &qV));
@@ -1176,13 +1190,13 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
     GL_TRY(gl_malloc(ctx, (size_t)nq * 4, (void **)&dist));
     GL_TRY(gl_malloc(ctx, (size_t)nq * 8, (void **)&idx));
     GL_TRY(gl_memcpy_h2d(ctx, raw, queries_u8_host, (size_t)(nq * D)));
-    GL_TRY(gl_lpips_search_features_u8(l, raw, nq, H, W, 0, qV, qn));
+    GL_TRY(features(nq, 0, qV, qn));
     GL_TRY(gl_keys_init(ctx, keys, nq));
     for (int64_t lo = 0; lo < n_eff; lo += chunk) {
         const int64_t m = n_eff - lo < chunk ? n_eff - lo : chunk;
         GL_TRY(gl_ctx_sync(ctx));                                  // raw is reused
         GL_TRY(gl_memcpy_h2d(ctx, raw, bank_u8_host + lo * D, (size_t)(m * D)));
-        GL_TRY(gl_lpips_search_features_u8(l, raw, m, H, W, 1, bV, bn));
+        GL_TRY(features(m, 1, bV, bn));
         GL_TRY(gl_feat_knn_h1(ctx, bV, bn, m, lo, qV, qn, nq, K1, keys));
     }
     GL_TRY(gl_keys_unpack_f32(ctx, keys, nq, dist, idx));
@@ -1190,6 +1204,7 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
     GL_TRY(gl_memcpy_d2h(ctx, idx_host, idx, (size_t)nq * 8));
 #undef GL_TRY
 done:
+    l->precision = precision_in;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(raw); (void)hipFree(qV); (void)hipFree(bV); (void)hipFree(qn); (void)hipFree(bn); (void)hipFree(keys); (void)hipFree(dist); (void)hipFree(idx);
     return rc;

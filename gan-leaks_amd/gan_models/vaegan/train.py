@@ -151,3 +151,10 @@ class Generator:
         return out
 
     __call__ = forward
+
+    def generate_u8(self, x):
+        """8-bit bank of the generator's samples (u8 DeviceArray [N,3,64,64], bank index = latent index), quantised as the image generate
+        branches do (gan_models/dcgan/train_torch.py:154-158,172).  The reference's VAEGAN sampler keeps floats (vaegan/sample.py:55-59)
+        and has no reader in fbb.py; this is what `attack(queries, GeneratedBank(generator, z))` consumes.  One forward =
+        one spectral-norm step, like forward()."""
+        return self.forward_device(x, False, True)[1]

@@ -45,6 +45,20 @@ def attack_case(seed, n_bank, n_pos, n_neg, res=64, sigma=10.0):
     return {"bank": bank, "pos": pos, "neg": neg, "pos_src": src}
 
 
+def lpips_big_case(name):
+    """(bank [8,3,H,W], queries [3,3,H,W]) u8 of the BASELINE configs[3]-shaped LPIPS fixtures `lpips_res256` (256 x 256, PGGAN-256's
+    image size) and `lpips_res128x256` (non-square): two queries are perturbed bank images, one is fresh"""
+    if name == "lpips_res256":
+        case = attack_case(41, 8, 2, 1, 256, sigma=20.0)
+        return case["bank"], np.concatenate([case["pos"], case["neg"]])
+    if name != "lpips_res128x256":
+        raise KeyError(name)
+    H, W = 128, 256
+    bank = np.stack([lowpass_u8_images(4200 + k, 1, 256)[0][:, 64:64 + H, :W] for k in range(8)])
+    q = np.concatenate([perturb_u8(43, bank[[6, 1]], 20.0), lowpass_u8_images(4300, 1, 256)[:, :, :H, :W]])
+    return np.ascontiguousarray(bank), np.ascontiguousarray(q)
+
+
 def dcgan_state_dict(seed=1234, z_dim=100, channels_img=3, features_g=64, prefix="gen.", gain=1.0):
     """Random DCGAN/WGAN-GP generator weights under the reference's key names
     (gan_models/dcgan/model_torch.py:75-96): gen.{0..3}.0.weight [Ci,Co,4,4],

@@ -180,11 +180,8 @@ def _vgg16_features_standin(sd_np):
     return feats
 
 
-def make_lpips(fbb):
-    """attack_models/lpips_pytorch/models/networks_basic.py:134-181 PNetLin.forward (+ :222-230 NetLinLayer,
-    util/util.py:70-73 normalize_tensor, pretrained_networks.py:96-134 vgg16 slices) with the vendored lin
-    weights (pretrained_models/v0.1/vgg.pth) and a seeded random backbone; and custom_knn driven with
-    the 'l2-lpips' formula of attack_models/utils.py:166-176."""
+def _ref_pnetlin():
+    """the reference's PNetLin (networks_basic.py:94-181) on a seeded random backbone + the vendored lin weights, in eval mode"""
     sd_np = synth.vgg16_state_dict(7)
     tv_models = sys.modules["torchvision.models"]
 
@@ -201,13 +198,26 @@ def make_lpips(fbb):
     lin_sd = torch.load(lin_path, map_location="cpu", weights_only=True)
     print("lin load:", net.load_state_dict(lin_sd, strict=False))
     net.eval()                                              # dist_model.py:100
-    np.savez(os.path.join(HERE, "lpips_lin_v0.1.npz"), **{"lin%d" % i: lin_sd["lin%d.model.1.weight" % i].numpy().reshape(-1) for i in range(5)})
+    return net, lin_sd
 
+
+def _ref_l2_lpips(net):
     def lpips_fn(x_hat, x_gt):                              # utils.py:168 -> PerceptualLoss.forward(pred=x, target=y) -> net(in0=target, in1=pred)
         return net.forward(x_gt, x_hat).view(-1)
 
     def loss(x_hat, x_gt):                                  # utils.py:171-177
         return 0.2 * lpips_fn(x_hat, x_gt) + torch.mean((x_gt - x_hat) ** 2, dim=[1, 2, 3])
+    return lpips_fn, loss
+
+
+def make_lpips(fbb):
+    """attack_models/lpips_pytorch/models/networks_basic.py:134-181 PNetLin.forward (+ :222-230 NetLinLayer,
+    util/util.py:70-73 normalize_tensor, pretrained_networks.py:96-134 vgg16 slices) with the vendored lin
+    weights (pretrained_models/v0.1/vgg.pth) and a seeded random backbone; and custom_knn driven with
+    the 'l2-lpips' formula of attack_models/utils.py:166-176."""
+    net, lin_sd = _ref_pnetlin()
+    np.savez(os.path.join(HERE, "lpips_lin_v0.1.npz"), **{"lin%d" % i: lin_sd["lin%d.model.1.weight" % i].numpy().reshape(-1) for i in range(5)})
+    lpips_fn, loss = _ref_l2_lpips(net)
 
     for name, (seed, nbank, npos, nneg, res, bs) in {"lpips_res32": (31, 40, 4, 4, 32, 16), "lpips_res64": (32, 24, 3, 3, 64, 8)}.items():
         case = synth.attack_case(seed, nbank, npos, nneg, res, sigma=20.0)
@@ -227,6 +237,28 @@ def make_lpips(fbb):
         np.savez(os.path.join(HERE, name + ".npz"), seed=seed, n_bank=nbank, n_pos=npos, n_neg=nneg, res=res, batch_size=bs,
                  vgg_seed=7, lpips=lp, dist=np.array(d, np.float64), idx=np.array(i, np.int64), tap_shapes=tap_shapes, tap_sums=tap_sums)
         print(name, "idx", i, "dist", np.round(d, 4), "lpips range", lp.min(), lp.max())
+
+
+def make_lpips_big(fbb):
+    """the same reference code as make_lpips at PGGAN-256's image size (BASELINE configs[3]) and at a non-square size:
+    PNetLin.forward (networks_basic.py:134-181) for the [Q, N] LPIPS matrix and fbb.custom_knn (fbb.py:73-88) under the
+    'l2-lpips' formula (utils.py:166-176), BATCH_SIZE 4"""
+    net, _ = _ref_pnetlin()
+    lpips_fn, loss = _ref_l2_lpips(net)
+    for name in ("lpips_res256", "lpips_res128x256"):
+        bank_u8, q_u8 = synth.lpips_big_case(name)
+        bank, q = to_ref_tensor(bank_u8), to_ref_tensor(q_u8)
+        with torch.no_grad():
+            lp = torch.stack([lpips_fn(bank, q[k:k + 1]) for k in range(len(q))]).numpy()
+        args = types.SimpleNamespace(BATCH_SIZE=4)
+        d, i = [], []
+        for sample in q:
+            dd, ii = fbb.custom_knn(bank, sample, loss, args)
+            d.append(dd)
+            i.append(ii)
+        np.savez(os.path.join(HERE, name + ".npz"), batch_size=4, vgg_seed=7, lpips=lp, dist=np.array(d, np.float64), idx=np.array(i, np.int64),
+                 shape=np.array(bank_u8.shape[2:]))
+        print(name, bank_u8.shape, "idx", i, "dist", np.round(d, 4), "lpips range", lp.min(), lp.max())
 
 
 PGGAN_CASES = [  # (z_dim, in_channels, steps, alpha)
@@ -255,6 +287,27 @@ def make_pggan(pg):
     with torch.no_grad():
         out["stack_g1"] = st(torch.from_numpy(synth.latent(3, 4, 64)), 2, 1.0, 1).numpy()
     np.savez(os.path.join(HERE, "pggan_gen.npz"), cases=np.array(PGGAN_CASES, np.float64), **out)
+
+
+PGGAN_BIG_CASES = [  # (z_dim, in_channels, steps, alpha, n): the 128 x 128 and 256 x 256 depths (BASELINE configs[3] is steps=6)
+    (64, 256, 5, 1.0, 2), (64, 256, 5, 0.4, 2), (64, 256, 6, 1.0, 2), (64, 256, 6, 0.4, 2),
+    (128, 512, 6, 1.0, 1),            # configs[3]'s own channel plan: 512 ... 512, 256 @64, 128 @128, 64 @256
+]
+
+
+def make_pggan_big(pg):
+    """gan_models/pggan/model_torch.py:75-88 at steps 5 and 6 (factors :6), both fade-in branches; stored as float32, compressed"""
+    out = {}
+    for ci, (z_dim, C, steps, alpha, n) in enumerate(PGGAN_BIG_CASES):
+        sd_np = synth.pggan_state_dict(4321 + C, z_dim, C)
+        g = pg.Generator(z_dim, C, 3)
+        g.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+        g.eval()
+        z = synth.latent(5, n, z_dim)
+        with torch.no_grad():
+            out["case%d" % ci] = g(torch.from_numpy(z), steps, alpha).numpy()
+        print("pggan big case", ci, out["case%d" % ci].shape, float(out["case%d" % ci].std()))
+    np.savez_compressed(os.path.join(HERE, "pggan_gen_big.npz"), cases=np.array(PGGAN_BIG_CASES, np.float64), **out)
 
 
 def make_medgan(mg):
@@ -372,6 +425,10 @@ if __name__ == "__main__":
     if "--pggan-only" in sys.argv:
         make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
         sys.exit(0)
+    if "--big-only" in sys.argv:         # the BASELINE configs[3]-shaped fixtures (a few minutes of CPU)
+        make_pggan_big(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
+        make_lpips_big(fbb)
+        sys.exit(0)
     if "--medgan-only" in sys.argv:
         make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
         sys.exit(0)
@@ -389,7 +446,10 @@ if __name__ == "__main__":
     dc = _refimport.load("gan_models/dcgan/model_torch.py", "ref_dcgan_model")
     wg = _refimport.load("gan_models/wgangp/model.py", "ref_wgangp_model")
     make_dcgan(dc, wg)
-    make_pggan(_refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model"))
+    pg = _refimport.load("gan_models/pggan/model_torch.py", "ref_pggan_model")
+    make_pggan(pg)
+    make_pggan_big(pg)
+    make_lpips_big(fbb)
     make_medgan(_refimport.load("gan_models/medgan/model.py", "ref_medgan_model"))
     make_zsplit()
     import subprocess

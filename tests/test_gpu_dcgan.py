@@ -217,8 +217,9 @@ def test_fused_tail_matches_separate_launches(gl, synth, oracle):
 
 @pytest.mark.parametrize("gain", [0.05, 1.0, 4.0])
 def test_split_arithmetic_is_fp32_class_for_any_weight_scale(gain, gl, synth, oracle):
-    """the split-fp16 path is never less accurate than the fp32-MFMA path against the fp64 oracle, from tiny weights (outputs ~0.1) to
-    weights that saturate tanh and amplify rounding (fp32 itself 3e-4 off at gain 4)"""
+    """the split-fp16 path is in the fp32-MFMA path's error class against the fp64 oracle -- enforced bound: at most 1.5 x that path's
+    error (+1e-7) on the same inputs; measured: at or below it at all three gains -- from tiny weights (outputs ~0.1) to weights that
+    saturate tanh and amplify rounding (fp32 itself 3e-4 off at gain 4)"""
     from ganleaks_amd.gan_models.dcgan.model_torch import Generator
     sd = synth.dcgan_state_dict(2, gain=gain)
     z = synth.latent(12, 32)
@@ -230,4 +231,5 @@ def test_split_arithmetic_is_fp32_class_for_any_weight_scale(gain, gl, synth, or
         g.set_precision(mode)
         err[mode] = np.abs(g.forward_device(z, True, False)[0].numpy()[:4] - ref).max()
         assert g._precision == mode
+    print("gain", gain, "max |err| vs fp64 oracle: split-fp16 %.3e, fp32 MFMA %.3e" % (err[1], err[0]))
     assert err[1] <= 1.5 * err[0] + 1e-7, err

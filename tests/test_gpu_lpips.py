@@ -253,3 +253,75 @@ def test_non_square_images(hw, gl, synth, model, lin, oracle):
         assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
     with pytest.raises(ValueError):
         gl.attack(q[:, :, :, :8], bank[:, :, :, :8], distance="l2-lpips", batch_size=8, lpips=model)
+
+
+@pytest.mark.parametrize("name", ["lpips_res256", "lpips_res128x256"])
+def test_config3_image_size_matches_reference(name, gl, synth, model, golden_dir):
+    """256 x 256 (PGGAN-256's images, BASELINE configs[3]) and a non-square 128 x 256 against the reference's own PNetLin + custom_knn
+    (tests/golden/make_golden.py make_lpips_big): both VGG16 arithmetic modes, both row formats, resident and streamed"""
+    from ganleaks_amd.attack_models.utils import Loss
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    bank, q = synth.lpips_big_case(name)
+    H, W = bank.shape[2:]
+    bs = int(g["batch_size"])
+    row = 2 * int(gl.Context.get().lib.gl_lpips_search_dim(H, W))
+    errs = {}
+    for precision in (1, 0):
+        for rows in ("fp16", "split"):
+            for budget in (None, 3 * row):                  # None: resident; 3 rows: bank in chunks, queries in slices
+                model.set_precision(precision)
+                model.search_rows = rows
+                try:
+                    kw = {} if budget is None else {"chunk_bytes": budget * (1 if rows == "fp16" else 2)}
+                    dist, idx = gl.attack(q, bank, distance="l2-lpips", batch_size=bs, lpips=model, **kw)
+                finally:
+                    model.set_precision(1)
+                    model.search_rows = "fp16"
+                assert np.array_equal(idx, g["idx"]), (precision, rows, budget)
+                errs[(precision, rows, budget is not None)] = float(np.abs(dist.astype(np.float64) - g["dist"]).max())
+    print(name, errs)
+    assert max(errs.values()) < ATOL, errs                  # north_star's bound
+    # K is 8.5 M values per row at 256 x 256: the fp32 accumulation of the dot product is what is left (DESIGN.md section 2)
+    assert max(errs.values()) < 3e-5, errs
+    # the pure LPIPS matrix row of query 0 through Loss.forward (split rows)
+    loss = Loss("l2-lpips", lpips=model)
+    loss(bank[:bs], q[:1])
+    assert np.abs(loss.loss_lpips - g["lpips"][0, :bs]).max() < 5e-6
+
+
+def test_host_one_call_falls_back_when_split_fp16_saturates(gl, synth, lin):
+    """VGG16 weights with a large first-layer gain push activations beyond the fp16 range of the split layout: gl_fbb_knn_lpips_host must notice
+    (gl_ctx_h3_saturations) and redo the features with fp32 products, not return clamped results with GL_OK"""
+    import ctypes
+    from ganleaks_amd import _lib
+    from ganleaks_amd.lpips import LpipsModel
+    lib = _lib.load()
+    ctx = gl.Context.get()
+    sd = {k: v.copy() for k, v in synth.vgg16_state_dict(7).items()}
+    sd["0.weight"] *= 3.0e4
+    hot = LpipsModel().load_state_dicts(sd, lin)
+    case = synth.attack_case(94, 48, 4, 3, 32, sigma=20.0)
+    bank = np.ascontiguousarray(case["bank"])
+    q = np.ascontiguousarray(np.concatenate([case["pos"], case["neg"]]))
+    ref = LpipsModel().load_state_dicts(sd, lin)
+    ref.set_precision(0)
+    d0, i0 = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=ref)
+    # the split path alone does saturate on these weights
+    ctx.h3_saturations()
+    check = hot.ctx.lib.gl_lpips_search_features_u8
+    fb = ctx.empty((len(q), int(lib.gl_lpips_search_dim(32, 32))), np.float16)
+    nb = ctx.empty((len(q),), np.float32)
+    assert check(hot._handle, ctypes.c_void_p(ctx.to_device(q).ptr), len(q), 32, 32, 0, ctypes.c_void_p(fb.ptr), ctypes.c_void_p(nb.ptr)) == 0
+    assert ctx.h3_saturations() > 0
+    p = ctypes.c_void_p
+    dist = np.empty(len(q), np.float32)
+    idx = np.empty(len(q), np.int64)
+    rc = lib.gl_fbb_knn_lpips_host(ctx.handle, hot._handle, bank.ctypes.data_as(p), len(bank), q.ctypes.data_as(p), len(q), 32, 32, 16, 0,
+                                   dist.ctypes.data_as(p), idx.ctypes.data_as(p))
+    assert rc == 0, lib.gl_last_error()
+    assert np.array_equal(idx, i0) and np.abs(dist - d0).max() < 5e-6
+    assert hot._precision == 1           # the caller's setting is restored
+    # and the Python entry does the same
+    with pytest.warns(UserWarning):
+        d1, i1 = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=hot)
+    assert np.array_equal(i1, i0) and np.abs(d1 - d0).max() < 5e-6

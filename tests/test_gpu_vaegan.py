@@ -76,3 +76,28 @@ def test_sample_script(tmp_path, synth):
     torch.save(torch.nn.Linear(2, 2), tmp_path / "netG.pt")       # a pickled module is refused, not executed
     with pytest.raises(ValueError):
         sample.main(sample.parse_args(["--model_dir", str(tmp_path)]))
+
+
+def test_vaegan_bank_attack_against_c_oracle(synth):
+    """the image half of BASELINE configs[4]: VAEGAN generate_u8 -> 8-bit bank -> exact L2 1-NN, against the C oracle
+    (mirror of the DCGAN / PGGAN bank tests)"""
+    import c_oracle
+    import ganleaks_amd as gl
+    import oracle
+    from ganleaks_amd.gan_models.vaegan.train import Generator
+    gen = Generator(100, 64)
+    gen.load_state_dict(synth.vaegan_state_dict(777, 100, 64))
+    z = synth.latent(14, 200)
+    bank = gen.eval().generate_u8(z)
+    hb = bank.numpy()
+    assert hb.shape == (200, 3, 64, 64) and hb.dtype == np.uint8
+    q = np.concatenate([synth.perturb_u8(3, hb[[7, 150, 199]], 5.0), synth.lowpass_u8_images(5, 3, 64)])
+    d, i = gl.attack(q, bank, batch_size=64)
+    od, oi, _ = c_oracle.knn_l2_u8(hb, q, 64)
+    assert np.array_equal(i, oi) and np.array_equal(d, od) and i[0] == 7 and i[1] == 150 and i[2] != 199
+    # and the codes are the quantisation of what forward() returns for the same spectral-norm state
+    gen2 = Generator(100, 64)
+    gen2.load_state_dict(synth.vaegan_state_dict(777, 100, 64))
+    f = gen2.eval()(z)
+    diff = hb.astype(np.int32) - oracle.quantize_to_u8(f).astype(np.int32)
+    assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 1e-3          # forward() and generate_u8 are separate launches of the same arithmetic

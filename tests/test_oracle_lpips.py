@@ -28,3 +28,21 @@ def test_lpips_oracle_matches_reference(name, synth, oracle, golden_dir):
     d, i, _ = lpips_oracle.knn_l2_lpips(sd, lin, bank, q, int(g["batch_size"]))
     assert np.array_equal(i, g["idx"])
     np.testing.assert_allclose(d.astype(np.float64), g["dist"], atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["lpips_res256", "lpips_res128x256"])
+def test_lpips_oracle_matches_reference_at_config3_size(name, synth, oracle, golden_dir):
+    """256 x 256 (PGGAN-256's images, BASELINE configs[3]) and a non-square size against the reference's PNetLin + custom_knn"""
+    import lpips_oracle
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    lin = np.load(os.path.join(golden_dir, "lpips_lin_v0.1.npz"))
+    lin = [lin["lin%d" % i] for i in range(5)]
+    sd = synth.vgg16_state_dict(int(g["vgg_seed"]))
+    bank_u8, q_u8 = synth.lpips_big_case(name)
+    assert tuple(bank_u8.shape[2:]) == tuple(g["shape"])
+    bank, q = oracle.dequantize_u8(bank_u8), oracle.dequantize_u8(q_u8)
+    d, i, tot = lpips_oracle.knn_l2_lpips(sd, lin, bank, q, int(g["batch_size"]))
+    assert np.array_equal(i, g["idx"])
+    np.testing.assert_allclose(d.astype(np.float64), g["dist"], atol=2e-6)
+    lp = lpips_oracle.lpips_matrix(sd, lin, q, bank)
+    np.testing.assert_allclose(lp, g["lpips"], atol=2e-6)
