@@ -115,6 +115,9 @@ int gl_ctx_create(int device, gl_ctx **out_ctx)
     gl_ctx *c = new gl_ctx();
     c->device = device;
     c->prof_on = false;
+    c->num_cu = prop.multiProcessorCount;
+    c->pair_scratch = nullptr;
+    c->pair_scratch_bytes = 0;
     GL_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     GL_HIP(hipMalloc((void **)&c->zero_page, 4096));
@@ -136,6 +139,7 @@ int gl_ctx_destroy(gl_ctx *ctx)
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     (void)hipFree(ctx->zero_page);
     (void)hipFree(ctx->h3_sat);
+    (void)hipFree(ctx->pair_scratch);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return GL_OK;

@@ -19,6 +19,9 @@ struct gl_ctx {
     hipStream_t stream;      // the stream work is enqueued on (own_stream or the caller's)
     float *zero_page;        // 4 KiB of zeros on the device: source for out-of-image taps
     int *h3_sat;             // device counter: split-fp16 stores that had to clamp to the fp16 range (gl_ctx_h3_saturations)
+    int num_cu;              // compute units of the device
+    char *pair_scratch;      // lazily allocated workspace of the persistent pairwise kernel: per-workgroup fp32 totals + cluster counters
+    size_t pair_scratch_bytes;
     bool prof_on;            // gl_prof_enable: bracket tagged kernel launches with HIP events
     std::vector<gl_prof_span> prof_spans;
     std::vector<hipEvent_t> prof_pool;

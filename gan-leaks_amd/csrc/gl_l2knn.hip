@@ -20,6 +20,7 @@
 // one 64-bit atomicMin per (query, wave) on key = S << 32 | global_index  -- smallest index wins
 // ties, as torch.min does (fbb.py:86), independent of tile / shard order.
 #include "gl_common.h"
+#include "gl_pair256.h"
 #include <cstdlib>
 
 namespace {
@@ -265,6 +266,66 @@ l2_knn_i8_256_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict_
     }
 }
 
+// The same tile on the shared software-pipelined main loop (gl_pair256.h): fragment reads of the next MFMA block are issued before
+// the current block, one barrier per slice.
+template <int DIAG, int SPREAD>
+__global__ void __launch_bounds__(512, 2)
+l2_knn_i8_256p_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                      const int8_t *__restrict__ query, const int32_t *__restrict__ query_norm, int64_t nq, int64_t stride,
+                      unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, int shift)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
+    int qt, nt;
+    {
+        constexpr int STRIP = 4;
+        const unsigned per_strip = (unsigned)STRIP * (unsigned)q_tiles;
+        const int strip = (int)(id / per_strip);
+        const unsigned r = id % per_strip;
+        const int width = n_tiles - strip * STRIP < STRIP ? n_tiles - strip * STRIP : STRIP;
+        nt = strip * STRIP + (int)(r % (unsigned)width);
+        qt = (int)(r / (unsigned)width);
+    }
+    const int64_t n0 = (int64_t)nt * BT, q0 = (int64_t)qt * BT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wq = wave & 3;
+    const int frow = lane & 15, fk = lane >> 4;
+
+    const gl_pair256::Source sa = gl_pair256::make_source(reinterpret_cast<const char *>(bank), n0, n_rows, stride, wave, lane);
+    const gl_pair256::Source sb = gl_pair256::make_source(reinterpret_cast<const char *>(query), q0, nq, stride, wave, lane);
+    v4i acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+    gl_pair256::mainloop<v4i, DIAG, SPREAD>(sa, sb, stride / TILE_K, smem, acc, wave, lane,
+                              [](const v4i &a, const v4i &b, const v4i &c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); });
+
+    const int64_t nbase = n0 + wn * 128 + fk * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t q = q0 + wq * 64 + j * 16 + frow;
+        const unsigned qn = q < nq ? (unsigned)query_norm[q] : 0u;
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = nbase + i * 16 + r;
+                const unsigned bn = n < n_rows ? (unsigned)bank_norm[n] : 0u;
+                const unsigned long long s = bn + qn - 2u * (unsigned)acc[i][j][r];       // exact modulo 2^32, and S < 2^32
+                const unsigned long long key = (s << shift) | (unsigned long long)(index_base + n);
+                if (n < n_rows && key < best) best = key;
+            }
+        unsigned long long o = __shfl_xor(best, 16, 64);
+        best = o < best ? o : best;
+        o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -297,7 +358,20 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
     if (d <= 66051 && force_tile != 128 && (force_tile == 256 || q256 * n256 >= 1024)) {
         GL_ONCE_PER_DEVICE(ctx, \
             GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BOPER)););
-        hipLaunchKernelGGL(l2_knn_i8_256_kernel, dim3((unsigned)(q256 * n256)), dim3(512), 4 * BOPER, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows, index_base,
+        const char *variant_env = getenv("GL_PAIR_VARIANT");          // read per call: tools/bench_pairwise.py alternates variants in one process
+    const int variant = variant_env ? atoi(variant_env) : 1;
+        GL_ONCE_PER_DEVICE(ctx, \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<3, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<4, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)););
+        auto k256 = variant == 0 ? l2_knn_i8_256_kernel : variant == 11 ? l2_knn_i8_256p_kernel<1, 8> : variant == 12 ? l2_knn_i8_256p_kernel<2, 8>
+                    : variant == 13 ? l2_knn_i8_256p_kernel<3, 8> : variant == 14 ? l2_knn_i8_256p_kernel<4, 8> : variant == 4 ? l2_knn_i8_256p_kernel<0, 4> : variant == 2 ? l2_knn_i8_256p_kernel<0, 1>
+                    : l2_knn_i8_256p_kernel<0, 8>;
+        hipLaunchKernelGGL(k256, dim3((unsigned)(q256 * n256)), dim3(512), 4 * BOPER, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows, index_base,
                            query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q256, (int)n256, shift);
         GL_LAUNCH_CHECK();
         return GL_OK;

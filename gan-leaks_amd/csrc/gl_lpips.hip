@@ -16,7 +16,9 @@
 // Convolutions reuse gather_conv_kernel (gl_conv.hip): 3x3 p1 = 9 taps; the first layer (3 input channels)
 // is im2col'ed by the input kernel into one 32-wide K slice (27 values + 5 zeros).
 #include "gl_conv.h"
+#include "gl_pair256.h"
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -494,6 +496,7 @@ __global__ void __launch_bounds__(256) rows_split_kernel(const float *__restrict
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 constexpr int FT = 128, FROW = 128, FOPER = FT * FROW;
+constexpr int kSplitSeg = 2048;          // slices (of 32 values) per accumulation segment
 
 __global__ void __launch_bounds__(256, 2)
 feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
@@ -530,11 +533,11 @@ feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_no
         for (int i = 0; i < 4; ++i) gl_glds16(b_src[i] + kt * FROW, buf + FOPER + (wave * 4 + i) * 1024);
     };
 
-    v4f acc[4][4];
+    v4f acc[4][4], tot[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = tot[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int64_t nk = K / 32;
     stage(0, smem);
@@ -562,7 +565,18 @@ feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_no
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
             }
+        if ((kt & (kSplitSeg - 1)) == kSplitSeg - 1) {
+            // two-level sum: a row of a 256 x 256 image is 8.2 M values, and one fp32 chain that long loses ~2e-5 of a distance
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { tot[i][j] += acc[i][j]; acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+        }
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += tot[i][j];
 
     // epilogue: C tile 16x16: column (query) = lane & 15, row (bank) = 4 * (lane >> 4) + reg
     const int64_t nbase = n0 + wn * 64 + fk * 4;
@@ -709,6 +723,178 @@ feat_knn_h1_kernel(const char *__restrict__ bank, const float *__restrict__ bank
         o = __shfl_xor(best, 32, 64);
         best = o < best ? o : best;
         if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+    }
+}
+
+// the same tile on the shared software-pipelined main loop (gl_pair256.h)
+template <int SPREAD>
+__global__ void __launch_bounds__(512, 2)
+feat_knn_h1p_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                    const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
+    int qt, nt;
+    {
+        constexpr int STRIP = 4;
+        const unsigned per_strip = (unsigned)STRIP * (unsigned)q_tiles;
+        const int strip = (int)(id / per_strip);
+        const unsigned r = id % per_strip;
+        const int width = n_tiles - strip * STRIP < STRIP ? n_tiles - strip * STRIP : STRIP;
+        nt = strip * STRIP + (int)(r % (unsigned)width);
+        qt = (int)(r / (unsigned)width);
+    }
+    const int64_t n0 = (int64_t)nt * GT, q0 = (int64_t)qt * GT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wq = wave & 3;
+    const int frow = lane & 15, fk = lane >> 4;
+    const gl_pair256::Source sa = gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
+    const gl_pair256::Source sb = gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
+    v4f acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    gl_pair256::mainloop<v8h, 0, SPREAD>(sa, sb, K1 / 64, smem, acc, wave, lane,
+                              [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); });
+
+    const float inv_s2 = 1.0f / (kVScale * kVScale);
+    const int64_t nbase = n0 + wn * 128 + fk * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t q = q0 + wq * 64 + j * 16 + frow;
+        const float qn = q < nq ? query_norm[q] : 0.0f;
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t n = nbase + i * 16 + r;
+                const float bn = n < n_rows ? bank_norm[n] : 0.0f;
+                const float d = fmaxf(fmaf(-2.0f * inv_s2, acc[i][j][r], __fadd_rn(qn, bn)), 0.0f);
+                const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
+                if (n < n_rows && key < best) best = key;
+            }
+        unsigned long long o = __shfl_xor(best, 16, 64);
+        best = o < best ? o : best;
+        o = __shfl_xor(best, 32, 64);
+        best = o < best ? o : best;
+        if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// feat_knn_h1c_kernel: the same search as ONE persistent launch of `clusters x members` workgroups (8 x 32 on an MI355X: one
+// workgroup per CU).  Why: K is 536 576 halves at 64 x 64 (8 384 slices, ~9 ms per tile) and 8.6 M at 256 x 256; with one
+// workgroup per tile the 32 tiles that share an XCD's L2 start at different times once the first wave of tiles has finished, sit
+// at unrelated K positions and stop sharing operand panels (measured: 3.5 TB fetched beyond L2 per launch at 10k x 100k, against
+// 1.6 TB if every 4 x 8 group of tiles walked K together).  Here the workgroups with the same blockIdx & 7 (dealt to one XCD by
+// the dispatcher; a different placement costs speed, never correctness) form a cluster that takes a super-tile of 4 bank x 8 query
+// tiles at a time and meets at a counter before every super-tile and every K segment.  The counter carries no data (every
+// workgroup's result goes to keys[] by atomicMin as before), the wait is bounded, so a missing member delays and cannot hang.
+//
+// K segments: after every SEG slices the fp32 accumulators are added into per-workgroup totals in HBM and cleared, which turns the
+// 266 000-step accumulation chain of a 256 x 256 image pair into a two-level sum (error of a distance 1.8e-5 -> ~1e-6).
+// ---------------------------------------------------------------------------------------------
+constexpr int kClusters = 8, kSuperN = 4, kSuperQ = 8;
+constexpr int kSegSlices = 2048;                 // 128 Ki halves of K per segment
+constexpr size_t kTotalsPerWg = 8 * 32 * 64 * sizeof(v4f);     // 256 KiB: 8 waves x 32 accumulator tiles x 64 lanes x 4 floats
+
+__device__ __forceinline__ void cluster_meet(unsigned *counter, unsigned target)
+{
+    // one lane arrives and polls; the counter only orders time (L2 sharing), no memory is handed over
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; spin < 40000; ++spin) {
+            if ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(512, 2)
+feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                    const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, int members)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int cluster = blockIdx.x & (kClusters - 1), member = blockIdx.x >> 3;
+    unsigned *counter = reinterpret_cast<unsigned *>(scratch) + cluster * 32;           // 128 B apart
+    v4f *totals = reinterpret_cast<v4f *>(scratch + 4096 + (size_t)blockIdx.x * kTotalsPerWg);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wq = wave & 3;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int sup_n = (n_tiles + kSuperN - 1) / kSuperN, sup_q = (q_tiles + kSuperQ - 1) / kSuperQ;
+    const int64_t nk = K1 / 64;
+    const int nseg = (int)((nk + kSegSlices - 1) / kSegSlices);
+    const float inv_s2 = 1.0f / (kVScale * kVScale);
+    v4f *my_tot = totals + (size_t)wave * 32 * 64 + lane;
+    unsigned episode = 0;
+
+    for (int s = cluster; s < sup_n * sup_q; s += kClusters) {
+        // the 8 clusters work on consecutive bank groups of one query group: the query panels of the moment are then shared chip-wide
+        const int sq = s / sup_n, sn = s % sup_n;
+        const int nt = sn * kSuperN + (member & (kSuperN - 1)), qt = sq * kSuperQ + (member >> 2);
+        const bool active = member < kSuperN * kSuperQ && nt < n_tiles && qt < q_tiles;
+        const int64_t n0 = (int64_t)nt * GT, q0 = (int64_t)qt * GT;
+        gl_pair256::Source sa = {}, sb = {};
+        if (active) {
+            sa = gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
+            sb = gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
+        }
+        v4f acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int seg = 0; seg < nseg; ++seg) {
+            cluster_meet(counter, (unsigned)members * ++episode);
+            if (!active) continue;
+            const int64_t k0 = (int64_t)seg * kSegSlices;
+            const int64_t len = nk - k0 < kSegSlices ? nk - k0 : kSegSlices;
+            gl_pair256::mainloop<v8h>(sa, sb, len, smem, acc, wave, lane,
+                                      [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }, k0 * 128);
+            __syncthreads();                             // all fragment reads of the segment are done before its buffers are refilled
+            if (nseg > 1) {
+                // totals (+)= accumulators; the last segment leaves the sum in the accumulators
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v4f *t = my_tot + (i * 4 + j) * 64;
+                        if (seg > 0) acc[i][j] += *t;
+                        if (seg + 1 < nseg) { *t = acc[i][j]; acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+                        __builtin_amdgcn_sched_barrier(0);       // one tile at a time: 32 loads in flight at once would not fit the register file
+                    }
+            }
+        }
+        if (!active) continue;
+        const int64_t nbase = n0 + wn * 128 + fk * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + wq * 64 + j * 16 + frow;
+            const float qn = q < nq ? query_norm[q] : 0.0f;
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t n = nbase + i * 16 + r;
+                    const float bn = n < n_rows ? bank_norm[n] : 0.0f;
+                    const float d = fmaxf(fmaf(-2.0f * inv_s2, acc[i][j][r], __fadd_rn(qn, bn)), 0.0f);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
+                    if (n < n_rows && key < best) best = key;
+                }
+            unsigned long long o = __shfl_xor(best, 16, 64);
+            best = o < best ? o : best;
+            o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+        }
     }
 }
 
@@ -1055,9 +1241,35 @@ int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm
     GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn_h1: grid too large");
     const int lds = 4 * GOPER;
     GL_ONCE_PER_DEVICE(ctx, \
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
-    hipLaunchKernelGGL(feat_knn_h1_kernel, dim3((unsigned)(q_tiles * n_tiles)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev), bank_norm_dev, n_rows,
+    const char *variant_env = getenv("GL_PAIR_VARIANT");          // read per call: tools/bench_pairwise.py alternates variants in one process
+    const int variant = variant_env ? atoi(variant_env) : 3;
+    // the persistent cluster form (any problem size; needs 32 workgroup slots per cluster, i.e. a whole MI355X)
+    const int members = ctx->num_cu / kClusters;
+    if (variant == 3 && members >= kSuperN * kSuperQ) {
+        const size_t need = 4096 + (size_t)kClusters * members * kTotalsPerWg;
+        if (ctx->pair_scratch_bytes < need) {
+            GL_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->pair_scratch);
+            ctx->pair_scratch = nullptr; ctx->pair_scratch_bytes = 0;
+            GL_HIP(hipMalloc((void **)&ctx->pair_scratch, need));
+            ctx->pair_scratch_bytes = need;
+        }
+        GL_ONCE_PER_DEVICE(ctx, \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
+        GL_HIP(hipMemsetAsync(ctx->pair_scratch, 0, 4096, ctx->stream));         // the cluster counters
+        hipLaunchKernelGGL(feat_knn_h1c_kernel, dim3((unsigned)(kClusters * members)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
+                           bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
+                           reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members);
+        GL_LAUNCH_CHECK();
+        return GL_OK;
+    }
+    auto kern = variant == 0 ? feat_knn_h1_kernel : variant == 4 ? feat_knn_h1p_kernel<4> : variant == 2 ? feat_knn_h1p_kernel<1> : feat_knn_h1p_kernel<8>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(q_tiles * n_tiles)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev), bank_norm_dev, n_rows,
                        index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
                        (int)n_tiles);
     GL_LAUNCH_CHECK();

@@ -34,7 +34,8 @@ typedef enum gl_status {
     GL_ERR_HIP = -2,       /* a HIP runtime call failed */
     GL_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
     GL_ERR_STATE = -4,     /* object not ready (weights missing, bank not set) */
-    GL_ERR_EMPTY_BANK = -5 /* bank shorter than one BATCH_SIZE: reference raises ValueError at fbb.py:83 */
+    GL_ERR_EMPTY_BANK = -5,/* bank shorter than one BATCH_SIZE: reference raises ValueError at fbb.py:83 */
+    GL_ERR_RCCL = -6       /* librccl missing, or an RCCL call failed (gl_comm_*) */
 } gl_status;
 
 typedef struct gl_ctx gl_ctx;       /* opaque: device + stream + scratch */
@@ -42,6 +43,7 @@ typedef struct gl_dcgan gl_dcgan;   /* opaque: packed DCGAN / WGAN-GP generator 
 typedef struct gl_lpips gl_lpips;   /* opaque: VGG16 + LPIPS v0.1 lin layers */
 typedef struct gl_pggan gl_pggan;   /* opaque: packed progressive-GAN generator */
 typedef struct gl_medgan gl_medgan; /* opaque: medGAN residual-MLP generator + autoencoder decoder */
+typedef struct gl_comm gl_comm;     /* opaque: one rank of an RCCL communicator, bound to a gl_ctx */
 
 /* ---------------------------------------------------------------- library / context */
 int gl_abi_version(void);
@@ -144,6 +146,27 @@ int gl_l2_rows_f32(gl_ctx *ctx, const float *x_hat_dev, int64_t b, const float *
  * Synchronises. Returns GL_ERR_EMPTY_BANK when n_bank < batch_size. */
 int gl_fbb_knn_l2_host(gl_ctx *ctx, const uint8_t *bank_u8_host, int64_t n_bank, const uint8_t *queries_u8_host, int64_t nq,
                        int64_t d, int64_t batch_size, float *dist_host, int64_t *idx_host);
+
+/* ---------------------------------------------------------------- sharded bank: the cross-GPU minimum (RCCL over xGMI) */
+/* The reference runs on one device (attack_models/fbb.py:40) and takes the minimum over the whole bank with torch.min (fbb.py:86).  With the bank
+ * sharded over GPUs every rank holds keys[q] = min over ITS rows, global indices inside; the minimum over ranks of the unsigned
+ * 64-bit keys is the single-device result bit for bit (smallest distance, then smallest global index).  One communicator rank per gl_ctx;
+ * librccl is bound at run time on the first gl_comm_* call (GL_ERR_RCCL if absent).
+ *   one process per GPU : rank 0 calls gl_comm_unique_id, the launcher carries the GL_COMM_ID_BYTES bytes to every rank (any out-of-band
+ *                         channel: torch.distributed's store, MPI, a file), every rank calls gl_comm_init_rank (collective, blocking);
+ *   one process, N GPUs : gl_comm_init_all on N contexts of N different devices; a thread per context may then call gl_allreduce_min_keys,
+ *                         or one thread issues all N calls between gl_comm_group_start / gl_comm_group_end. */
+#define GL_COMM_ID_BYTES 128
+int gl_comm_unique_id(void *id_out_host);                                                     /* ncclGetUniqueId */
+int gl_comm_init_rank(gl_ctx *ctx, const void *id_host, int rank, int nranks, gl_comm **out);  /* ncclCommInitRank on ctx's device */
+int gl_comm_init_all(gl_ctx *const *ctxs, int n, gl_comm **out_comms);                         /* ncclCommInitAll; out_comms[n] */
+int gl_comm_destroy(gl_comm *comm);
+int gl_comm_rank(const gl_comm *comm, int *out_rank, int *out_nranks);
+/* keys_dev[q] = min over ranks of keys_dev[q], in place: ncclAllReduce(ncclMin, ncclUint64) queued on the context's stream -- behind the search
+ * kernel that wrote the keys, ahead of gl_keys_unpack*; no host synchronisation.  Q x 8 bytes (80 KB at Q = 10^4): latency-bound. */
+int gl_allreduce_min_keys(gl_comm *comm, uint64_t *keys_dev, int64_t nq);
+int gl_comm_group_start(void);                                                                 /* ncclGroupStart */
+int gl_comm_group_end(void);                                                                   /* ncclGroupEnd */
 
 /* ---------------------------------------------------------------- DCGAN / WGAN-GP generator */
 /* gan_models/dcgan/model_torch.py:75-96 == gan_models/wgangp/model.py:37-58:

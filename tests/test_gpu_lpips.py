@@ -281,8 +281,9 @@ def test_config3_image_size_matches_reference(name, gl, synth, model, golden_dir
                 errs[(precision, rows, budget is not None)] = float(np.abs(dist.astype(np.float64) - g["dist"]).max())
     print(name, errs)
     assert max(errs.values()) < ATOL, errs                  # north_star's bound
-    # K is 8.5 M values per row at 256 x 256: the fp32 accumulation of the dot product is what is left
-    assert max(errs.values()) < 3e-5, errs
+    # K is 8.5 M values per row at 256 x 256: a single fp32 accumulation chain over it was 1.9e-5 off; the kernels sum in segments
+    # (two-level), measured 6e-7 .. 1.4e-6
+    assert max(errs.values()) < 5e-6, errs
     # the pure LPIPS matrix row of query 0 through Loss.forward (split rows)
     loss = Loss("l2-lpips", lpips=model)
     loss(bank[:bs], q[:1])
