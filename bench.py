@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the fbb attack path on MI355X.
 
-Workload (BASELINE.json configs[1]): DCGAN-64 generator, 10 000 queries x 100 000-sample bank, L2.
-One "step" = one full pass of the hot path with z, weights and the query codes already resident in
-HBM:   z --fp32-MFMA generator--> 8-bit bank --prepare--> int8-MFMA pairwise L2 + argmin
+Headline workload (BASELINE.json configs[1]): DCGAN-64 generator, 10 000 queries x 100 000-sample bank, L2.
+One "step" = one full pass of the hot path with z, weights and the query codes already resident in HBM:
+       z --split-fp16 MFMA generator--> 8-bit bank --prepare--> int8-MFMA pairwise L2 + argmin
        [--RCCL min over ranks-->] (dist[Q], idx[Q]) on the host.
-value = queries / step time (whole job, all ranks).  N > 1 shards the bank (strong scaling: the
-problem is fixed), every rank keeps all queries, one all-reduce(min) of Q packed keys.
+value = queries / step time (whole job, all ranks).  N > 1 shards the bank (strong scaling: the problem is fixed), every rank keeps
+all queries, one all-reduce(min) of Q packed keys -- issued by libganleaks_hip.so itself (gl_allreduce_min_keys: RCCL on the
+context's stream); torch.distributed is the launcher's rendezvous only (gloo: carries the RCCL unique id, the barrier and the
+max-over-ranks of the timing).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (fields: see the project brief); progress goes to stderr.
+Prints ONE JSON line on rank 0 (fields: see the project brief); progress goes to stderr.  With the default flags on one GPU the line
+also carries two further measurements of the same run:
+    "secondary"       BASELINE configs[2]: the same 10k x 100k problem under the reference's own fbb distance 0.2*LPIPS + L2
+                      (attack_models/fbb.py:148), with its own roofline, parity block and cpu_baseline
+    "secondary_fp32"  the headline workload with strict fp32 MFMA products in the generator (--gen-precision 0)
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -28,80 +35,89 @@ sys.path.insert(0, ROOT)
 
 F_GATHER_PER_IMG = 2.0 * (100 * 1024 * 16 + 16 * 1024 * 512 * 16 + 64 * 512 * 256 * 16 + 256 * 256 * 128 * 16)  # layers 0-3
 F_RGB_PER_IMG = 2.0 * (1024 * 128 * 3 * 16)                                                                       # layer 4
+F_VGG_PER_IMG = 2.0 * 1252.8e6   # 13 convs at 64x64
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: fp16/bf16 MFMA, dense
 PEAK_I8_MFMA_TOPS = 5000.0       # 2 x the ~2.5 PF bf16 dense peak (same cycles at twice the K)
 PEAK_HBM_GBS = 8000.0
+D = 3 * 64 * 64
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--queries", type=int, default=10000)
-    ap.add_argument("--bank", type=int, default=100000)
-    ap.add_argument("--batch-size", type=int, default=64)
-    ap.add_argument("--chunk", type=int, default=0, help="generator images per pass (0 = library default)")
-    ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed for the CPU baseline (0 = skip)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(16, usable cores))")
-    ap.add_argument("--check-queries", type=int, default=64, help="queries checked against the oracle after the run")
-    ap.add_argument("--gen-precision", type=int, default=1, choices=[0, 1],
-                    help="generator arithmetic: 1 = split-fp16 (three fp16 MFMAs per product, default), 0 = fp32 MFMA")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal: several ranks may then share one GPU)")
-    ap.add_argument("--no-balance", action="store_true",
-                    help="N > 1: equal bank shards instead of shards sized by each rank's measured generator speed")
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="stop the CPU baseline after this many seconds (at least 8 queries are timed)")
-    ap.add_argument("--feat-rows", default="fp16", choices=["fp16", "split"],
-                    help="l2-lpips only: rows of the nearest-neighbour search: fp16 = one half per LPIPS value (gl_feat_knn_h1, default), "
-                         "split = hi + lo halves of everything (gl_feat_knn)")
-    ap.add_argument("--distance", default="l2", choices=["l2", "l2-lpips"],
-                    help="l2 = BASELINE configs[1] (default, the headline); l2-lpips = configs[2] (0.2*LPIPS+L2; needs ~2 MB of HBM per image)")
-    args = ap.parse_args()
+class Job:
+    """what one process of the job holds: its rank, its GPU context, the launcher's process group and the native communicator"""
+    pass
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs the torch.distributed launcher (see module docstring)" % args.gpus)
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
+def setup_job(args):
     import torch
     import ganleaks_amd as gl
     from ganleaks_amd import shard
+    job = Job()
+    job.rank = int(os.environ.get("RANK", "0"))
+    job.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    job.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if job.world != args.gpus:
+        if job.world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs the torch.distributed launcher (see module docstring)" % args.gpus)
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, job.world))
+    ndev = torch.cuda.device_count()
+    share = args.collective == "gloo"                 # rehearsal: several ranks may share one GPU, keys are reduced through host memory
+    job.dev = job.local_rank % max(ndev, 1) if share else job.local_rank
+    if job.dev >= ndev:
+        raise SystemExit("rank %d needs GPU %d but only %d visible" % (job.rank, job.dev, ndev))
+    torch.cuda.set_device(job.dev)
+    job.torch, job.gl, job.shard = torch, gl, shard
+    job.ctx = gl.Context.get(job.dev)
+    job.lib = job.ctx.lib
+    job.dist, job.comm, job.nccl_group, job.collective = None, None, None, "none"
+    if job.world > 1:
+        import torch.distributed as dist
+        job.dist = dist
+        dist.init_process_group("gloo")               # rendezvous, barrier, timing max: CPU tensors only
+        job.collective = args.collective
+        if args.collective == "native":
+            ok = 1
+            try:
+                job.comm = shard.make_comm(job.ctx)
+                keys = job.ctx.to_device(np.full(1024, job.rank + 7, np.uint64))
+                job.comm.allreduce_min_keys(keys)      # RCCL connects lazily on the first collective: part of setup
+                ok = int(keys.numpy()[0] == 7)
+            except Exception as e:  # noqa: BLE001
+                log("[rank %d] native RCCL communicator failed: %s" % (job.rank, e))
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                log("[rank %d] falling back to torch.distributed's nccl backend for the key reduction" % job.rank)
+                job.comm = None
+                job.collective = "torch"
+        if job.collective == "torch":
+            job.nccl_group = dist.new_group(backend="nccl")
+            warm = torch.zeros(1024, dtype=torch.int64, device="cuda:%d" % job.dev)
+            dist.all_reduce(warm, op=dist.ReduceOp.MIN, group=job.nccl_group)
+            torch.cuda.synchronize()
+    return job
+
+
+def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline):
+    """one workload on this job: returns the JSON line (rank 0) or None"""
+    torch, gl, shard, ctx, lib, dist = job.torch, job.gl, job.shard, job.ctx, job.lib, job.dist
     from ganleaks_amd._lib import check
     from ganleaks_amd.attack_models.eval_roc import plot_roc
     from ganleaks_amd.gan_models.dcgan.model_torch import Generator
-
-    ndev = torch.cuda.device_count()
-    dev = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)   # gloo rehearsal: ranks may share a GPU
-    if dev >= ndev:
-        raise SystemExit("rank %d needs GPU %d but only %d visible" % (rank, dev, ndev))
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo")
-    ctx = gl.Context.get(dev)
-    lib = ctx.lib
     p = ctypes.c_void_p
     synth = gl.synth
-
+    rank, world = job.rank, job.world
     Q, N, B = args.queries, args.bank, args.batch_size
-    D = 3 * 64 * 64
     bounds = shard.shard_bounds(N, B, world)
     n_eff = bounds[-1]
     lo, hi = bounds[rank], bounds[rank + 1]
     n_loc = hi - lo
+    lpips_mode = distance == "l2-lpips"
 
     # ---------------------------------------------------------------- setup (untimed)
     t_setup = time.time()
@@ -110,7 +126,7 @@ def main():
     gen.load_state_dict(sd)
     if args.chunk:
         gen.set_chunk(args.chunk)
-    gen.set_precision(args.gen_precision)
+    gen.set_precision(gen_precision)
     z_all = synth.latent(1, N)                               # the bank's latents; bank index = z index
     shard_note = "equal shards"
     if world > 1 and not args.no_balance:
@@ -129,8 +145,6 @@ def main():
             if it >= 2:
                 times.append(e0.elapsed_ms_until(e1))
         mine = torch.tensor([float(np.median(times))], dtype=torch.float64)
-        if args.backend == "nccl":
-            mine = mine.cuda()
         allt = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allt, mine)
         ms = [float(t.item()) for t in allt]
@@ -140,8 +154,10 @@ def main():
         shard_note = "shards sized by measured generator speed (%s ms per 4096 images)" % ", ".join("%.2f" % t for t in ms)
         del zc, uc
     z_dev = ctx.to_device(z_all[lo:hi].reshape(n_loc, 100))
-    # queries: both classes are fresh generator samples (z streams disjoint from the bank's) with pixel noise;
-    # members get the smaller noise, so they sit closer to the bank on average and the AUROC is non-degenerate
+    # queries: both classes are fresh generator samples (z streams disjoint from the bank's) with pixel noise; members get the smaller noise,
+    # so they sit closer to the bank on average and the AUROC is non-degenerate.  (SURVEY 8(d) proposed low-pass random images as
+    # negatives; generator samples keep both classes on the generator's manifold, which is the harder and more realistic case.
+    # Throughput does not depend on the choice.)
     n_pos = Q // 2
     pos = synth.perturb_u8(5, gen.generate_u8(synth.latent(2, n_pos)).numpy(), 0.05 * 127.5)
     neg = synth.perturb_u8(6, gen.generate_u8(synth.latent(3, Q - n_pos)).numpy(), 0.10 * 127.5)
@@ -149,12 +165,13 @@ def main():
     q_dev = ctx.to_device(queries_u8.reshape(Q, D))
 
     lp_model = None
-    F_VGG_PER_IMG = 2.0 * 1252.8e6          # 13 convs at 64x64
-    if args.distance == "l2-lpips":
+    vgg_sd = lin = None
+    if lpips_mode:
         from ganleaks_amd.lpips import LpipsModel
         lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
-        lp_model = LpipsModel(ctx).load_state_dicts(synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
-        lp_model.set_precision(args.gen_precision)
+        vgg_sd = synth.vgg16_state_dict(7)
+        lp_model = LpipsModel(ctx).load_state_dicts(vgg_sd, {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
+        lp_model.set_precision(gen_precision)
         KF_ALG = int(lib.gl_lpips_feature_dim(64, 64))          # 512 000: the contraction length the roofline is priced on
         h1 = args.feat_rows == "fp16"
         KF = int(lib.gl_lpips_search_dim(64, 64)) if h1 else KF_ALG
@@ -168,24 +185,20 @@ def main():
 
     stride = int(lib.gl_l2_row_stride(D))
     bank_u8 = ctx.empty((n_loc, D), np.uint8)
-    bank_i8 = ctx.empty((n_loc, stride), np.int8)
-    bank_nrm = ctx.empty((n_loc,), np.int32)
-    q_i8 = ctx.empty((Q, stride), np.int8)
-    q_nrm = ctx.empty((Q,), np.int32)
+    if not lpips_mode:
+        bank_i8 = ctx.empty((n_loc, stride), np.int8)
+        bank_nrm = ctx.empty((n_loc,), np.int32)
+        q_i8 = ctx.empty((Q, stride), np.int8)
+        q_nrm = ctx.empty((Q,), np.int32)
     keys = ctx.empty((Q,), np.uint64)
     dist_dev = ctx.empty((Q,), np.float32)
     idx_dev = ctx.empty((Q,), np.int64)
     out_dist = np.empty(Q, np.float32)
     out_idx = np.empty(Q, np.int64)
     keys_t = None
-    if world > 1:
-        keys_t = torch.as_tensor(keys.view((Q,), np.int64), device="cuda:%d" % dev)
-        # communicator set-up (RCCL connects lazily on the first collective of a given size class) belongs to setup, also when --warmup 0
-        warm = torch.zeros(Q, dtype=torch.int64, device="cuda:%d" % dev)
-        dist.all_reduce(warm, op=dist.ReduceOp.MIN)
-        torch.cuda.synchronize()
-        del warm
-    log("[rank %d] setup %.1fs: bank rows [%d,%d) of n_eff=%d, %d queries" % (rank, time.time() - t_setup, lo, hi, n_eff, Q))
+    if job.collective == "torch":
+        keys_t = torch.as_tensor(keys.view((Q,), np.int64), device="cuda:%d" % job.dev)
+    log("[rank %d] %s setup %.1fs: bank rows [%d,%d) of n_eff=%d, %d queries" % (rank, distance, time.time() - t_setup, lo, hi, n_eff, Q))
 
     ev = [ctx.event() for _ in range(4)]
 
@@ -212,10 +225,17 @@ def main():
             check(knn(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr)))
         if timed_phases is not None:
             ev[2].record()
-        if world > 1:
+        # the path's one exchange step: the minimum over ranks of Q packed keys (80 KB)
+        if job.comm is not None:
+            job.comm.allreduce_min_keys(keys)                     # RCCL on the library's stream: no host synchronisation
+        elif job.collective == "torch":
             ctx.sync()                                            # keys are complete on the library's stream
-            dist.all_reduce(keys_t, op=dist.ReduceOp.MIN)         # the path's one exchange step: Q packed keys (80 KB)
+            dist.all_reduce(keys_t, op=dist.ReduceOp.MIN, group=job.nccl_group)
             torch.cuda.current_stream().synchronize()             # reduced keys visible before the unpack kernel
+        elif job.collective == "gloo":
+            host = torch.from_numpy(keys.numpy().view(np.int64))
+            dist.all_reduce(host, op=dist.ReduceOp.MIN)
+            check(lib.gl_memcpy_h2d(ctx.handle, p(keys.ptr), host.numpy().ctypes.data_as(p), Q * 8))
         if lp_model is None:
             check(lib.gl_keys_unpack(ctx.handle, p(keys.ptr), Q, D, p(dist_dev.ptr), p(idx_dev.ptr)))
         else:
@@ -234,16 +254,17 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
+            ctx.sync()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     phases = {"generator_ms": 0.0, "distance_ms": 0.0, "reduce_unpack_d2h_ms": 0.0}
     ctx.prof_reset()
     ctx.prof_enable(True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step(phases)
     fence()
     elapsed = time.perf_counter() - t0
@@ -252,18 +273,18 @@ def main():
     ctx.prof_reset()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = Q / (elapsed / args.steps)
+    ms_per_step = 1e3 * elapsed / steps
+    value = Q / (elapsed / steps)
 
     # ---------------------------------------------------------------- per-kernel rooflines (this rank's launches)
     def kernel_entry(name, alg_per_step, bound, peak, unit, scale, executed_factor=1.0, note=None):
         ms, launches = prof[name]
         if launches == 0 or ms <= 0:
             return None
-        per_launch = alg_per_step * args.steps / launches
+        per_launch = alg_per_step * steps / launches
         avg_ms = ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / scale
         e = {"kernel": name, "bound": bound, "achieved": round(achieved, 2), "peak": peak, "unit": unit,
@@ -280,7 +301,7 @@ def main():
             e["note"] = note
         return e
 
-    split = args.gen_precision == 1
+    split = gen_precision == 1
     conv_peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
     kernels = [
         # all five ConvTranspose layers run in gather_conv (the 3-channel tail as a 48-column scatter-form GEMM)
@@ -295,28 +316,30 @@ def main():
                                                     else "split-fp16 contraction: 3 fp16 MFMAs per product")),
         # col2im + tanh + quantise: reads P [1024][48] fp32, writes 12288 codes per image
         kernel_entry("convt_rgb", n_loc * (1024 * 48 * 4 + 12288.0), "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
-        kernel_entry("l2_prepare", 2.0 * (n_loc + Q) * D, "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
+        kernel_entry("l2_prepare", 0 if lp_model is not None else 2.0 * (n_loc + Q) * D, "hbm", PEAK_HBM_GBS, "GB/s", 1e9),
     ]
     kernels = [k for k in kernels if k and k["alg_per_launch"] > 0]
     # HBM-side traffic per launch from the PMC counters: cannot be collected from inside this process; taken from the committed
-    # rocprofv3 --pmc passes of this exact workload (profiles/r01/pmc_traffic_default.json says how), null for any other workload
-    import glob
-    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic_default.json")))     # the latest round's passes
-    traffic_file = traffic_files[-1] if traffic_files else ""
-    if traffic_file and world == 1 and Q == 10000 and N == 100000 and lp_model is None and split:
-        with open(traffic_file) as f:
+    # rocprofv3 --pmc passes of this exact workload (tools/pmc_summary.py says how), null for any other workload
+    name = ("pmc_traffic_default.json" if split else "pmc_traffic_fp32.json") if lp_model is None else "pmc_traffic_l2lpips.json"
+    traffic_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))     # the latest round's passes
+    if traffic_files and world == 1 and Q == 10000 and N == 100000 and (lp_model is None or (split and h1)):
+        with open(traffic_files[-1]) as f:
             tr = json.load(f)
         for k in kernels:
-            if k["kernel"] in tr:
+            if k["kernel"] in tr and "hbm_bytes_per_launch" in tr[k["kernel"]]:
                 k["traffic"] = round(tr[k["kernel"]]["hbm_bytes_per_launch"])
+                k["traffic_source"] = os.path.relpath(traffic_files[-1], ROOT)
     dominant = max(kernels, key=lambda k: k["avg_ms"] * k["launches"])
+    if lp_model is not None:
+        dominant = [k for k in kernels if k["kernel"] == "feat_knn"][0]      # the pairwise contraction is this mode's own kernel
     roofline = {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
-    for k in ("executed_mfma", "executed_frac", "frac_of_f32_mfma_peak", "note"):
+    for k in ("executed_mfma", "executed_frac", "frac_of_f32_mfma_peak", "note", "traffic_source"):
         if k in dominant:
             roofline[k] = dominant[k]
     roofline["kernel"] = dominant["kernel"]
     roofline["avg_launch_ms"] = dominant["avg_ms"]
-    roofline["launches_per_step"] = dominant["launches"] / args.steps
+    roofline["launches_per_step"] = dominant["launches"] / steps
 
     # ---------------------------------------------------------------- parity check against the oracle (untimed)
     parity = None
@@ -326,10 +349,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import lpips_oracle
         import oracle as np_oracle
-        lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
         sub_bank = bank_u8.numpy()[:256].reshape(256, 3, 64, 64)
         sel = np.linspace(0, Q - 1, 8).astype(np.int64)
-        od, oi, _ = lpips_oracle.knn_l2_lpips(synth.vgg16_state_dict(7), [lin["lin%d" % i] for i in range(5)], np_oracle.dequantize_u8(sub_bank),
+        od, oi, _ = lpips_oracle.knn_l2_lpips(vgg_sd, [lin["lin%d" % i] for i in range(5)], np_oracle.dequantize_u8(sub_bank),
                                               np_oracle.dequantize_u8(queries_u8[sel]), 64)
         gd, gi = gl.attack(queries_u8[sel], sub_bank, distance="l2-lpips", batch_size=64, lpips=lp_model)
         parity = {"queries_checked": 8, "bank_checked": 256, "idx_equal": bool(np.array_equal(gi, oi)),
@@ -343,10 +365,8 @@ def main():
         okeys = (os_.astype(np.uint64) << np.uint64(32)) | (oi + lo).astype(np.uint64)
         if world > 1:
             tk = torch.from_numpy(okeys.view(np.int64).copy())
-            if args.backend == "nccl":
-                tk = tk.cuda()
             dist.all_reduce(tk, op=dist.ReduceOp.MIN)
-            okeys = tk.cpu().numpy().view(np.uint64)
+            okeys = tk.numpy().view(np.uint64)
         o_idx = (okeys & np.uint64(0xFFFFFFFF)).astype(np.int64)
         o_dist = ((okeys >> np.uint64(32)).astype(np.float64) * (4.0 / (65025.0 * D))).astype(np.float32)
         parity = {"queries_checked": int(nchk), "idx_equal": bool(np.array_equal(o_idx, out_idx[sel])),
@@ -357,65 +377,148 @@ def main():
 
     # ---------------------------------------------------------------- CPU baseline (rank 0, N = 1 only)
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_queries > 0 and lp_model is None:
+    if rank == 0 and world == 1 and cpu_leg and args.cpu_queries > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import torch_port
         usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         torch.set_num_threads(args.cpu_threads or min(16, usable))     # the 1-GPU box's CPU share is 16 cores
-        nq_cpu = min(args.cpu_queries, Q)
-        sel = np.linspace(0, Q - 1, nq_cpu).astype(np.int64)
         host_bank = bank_u8.numpy().reshape(n_loc, 3, 64, 64)
-        t_prep = time.time()
-        bank_f = torch_port.dequantize(host_bank)                 # what fbb.main builds (fbb.py:134-135)
-        q_f = torch_port.dequantize(queries_u8[sel])
-        log("[cpu] bank dequantised to fp32 in %.1fs; timing %d queries x %d samples on %d threads" %
-            (time.time() - t_prep, nq_cpu, n_loc, torch.get_num_threads()))
-        torch_port.custom_knn(bank_f[:6400], q_f[0], torch_port.l2_loss, B)      # warm-up
-        tc = time.perf_counter()
-        cd, ci = [], []
-        for k in range(nq_cpu):
-            d_, i_ = torch_port.custom_knn(bank_f, q_f[k], torch_port.l2_loss, B)
-            cd.append(d_)
-            ci.append(i_)
-            if k + 1 >= 8 and time.perf_counter() - tc > args.cpu_seconds:      # bounded sample: host speed varies a lot between boxes
-                break
-        cpu_s = time.perf_counter() - tc
-        nq_cpu = len(cd)
-        sel = sel[:nq_cpu]
-        cpu = {"value": round(nq_cpu / cpu_s, 4), "unit": "query-images/s", "cores": int(torch.get_num_threads()), "kind": "port",
-               "sample": "%d of the %d queries x the full %d-sample bank, BATCH_SIZE %d, PyTorch-CPU restatement of fbb.custom_knn "
-                         "(oracle/torch_port.py); bank search only, the CPU does not run the generator" % (nq_cpu, Q, n_loc, B),
-               "seconds": round(cpu_s, 2),
-               "idx_equal_gpu": bool(np.array_equal(np.array(ci), out_idx[sel])),
-               "max_abs_dist_diff_vs_gpu": float(np.abs(np.array(cd) - out_dist[sel]).max())}
-        del bank_f
+        if lp_model is None:
+            nq_cpu = min(args.cpu_queries, Q)
+            sel = np.linspace(0, Q - 1, nq_cpu).astype(np.int64)
+            t_prep = time.time()
+            bank_f = torch_port.dequantize(host_bank)                 # what fbb.main builds (fbb.py:134-135)
+            q_f = torch_port.dequantize(queries_u8[sel])
+            log("[cpu] bank dequantised to fp32 in %.1fs; timing %d queries x %d samples on %d threads" %
+                (time.time() - t_prep, nq_cpu, n_loc, torch.get_num_threads()))
+            torch_port.custom_knn(bank_f[:6400], q_f[0], torch_port.l2_loss, B)      # warm-up
+            tc = time.perf_counter()
+            cd, ci = [], []
+            for k in range(nq_cpu):
+                d_, i_ = torch_port.custom_knn(bank_f, q_f[k], torch_port.l2_loss, B)
+                cd.append(d_)
+                ci.append(i_)
+                if k + 1 >= 8 and time.perf_counter() - tc > args.cpu_seconds:      # bounded sample: host speed varies a lot between boxes
+                    break
+            cpu_s = time.perf_counter() - tc
+            nq_cpu = len(cd)
+            sel = sel[:nq_cpu]
+            cpu = {"value": round(nq_cpu / cpu_s, 4), "unit": "query-images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                   "sample": "%d of the %d queries x the full %d-sample bank, BATCH_SIZE %d, PyTorch-CPU restatement of fbb.custom_knn "
+                             "(oracle/torch_port.py); bank search only, the CPU does not run the generator" % (nq_cpu, Q, n_loc, B),
+                   "seconds": round(cpu_s, 2),
+                   "idx_equal_gpu": bool(np.array_equal(np.array(ci), out_idx[sel])),
+                   "max_abs_dist_diff_vs_gpu": float(np.abs(np.array(cd) - out_dist[sel]).max())}
+            del bank_f
+        else:
+            # the reference's literal loop (fbb.py:77-81 with Loss('l2-lpips')): one VGG16 + LPIPS evaluation of 64 bank images + the query per
+            # (query, batch); 10^4 x 1 562 of them make the job.  SURVEY 8(d): time >= 3 batches of 64 pairs after a warm-up, scale by Q * N_eff.
+            loss = torch_port.make_l2_lpips_loss(vgg_sd, [lin["lin%d" % i] for i in range(5)])
+            bank_f = torch_port.dequantize(host_bank[:64 * 8])
+            q_f = torch_port.dequantize(queries_u8[:1])
+            loss(bank_f[:64], q_f)                                    # warm-up
+            tc = time.perf_counter()
+            nb, vals = 0, []
+            while nb < 8 and (nb < 3 or time.perf_counter() - tc < args.cpu_seconds):
+                vals.append(loss(bank_f[64 * nb:64 * (nb + 1)], q_f).detach().numpy())
+                nb += 1
+            cpu_s = time.perf_counter() - tc
+            pairs_s = 64 * nb / cpu_s
+            from ganleaks_amd.attack_models.utils import Loss
+            dev_loss = Loss("l2-lpips", lpips=lp_model)
+            dv = np.concatenate([np.asarray(dev_loss(host_bank[64 * b:64 * (b + 1)], queries_u8[:1])) for b in range(nb)])
+            cpu = {"value": round(pairs_s / n_eff, 8), "unit": "query-images/s", "cores": int(torch.get_num_threads()), "kind": "port",
+                   "sample": "%d batches of 64 (bank image, query) pairs under 0.2*LPIPS+L2, autograd on as in the reference, PyTorch-CPU restatement of "
+                             "Loss('l2-lpips').forward + PNetLin (oracle/torch_port.py); scaled by the %d pairs one query costs the reference "
+                             "(VGG16 on 65 images per batch of 64)" % (nb, n_eff),
+                   "pairs_per_s": round(pairs_s, 2), "seconds": round(cpu_s, 2),
+                   "max_abs_loss_diff_vs_gpu": float(np.abs(np.concatenate(vals) - dv).max())}
 
-    if rank == 0:
-        line = {
-            "metric": "attack query-images/sec (10k queries x 100k samples) + AUROC delta vs ref",
-            "value": round(value, 2), "unit": "query-images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": (("split-f16 (hi+lo, f32 accumulate; generator)" if split else "f32 (generator)") + " + i8->i32 exact (distance)") if lp_model is None
-            else ("split-f16" if split else "f32") + " (generator, VGG16) + " + ("f16 search rows" if args.feat_rows == "fp16" else "split-f16") + " (LPIPS contraction)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)" if lp_model is None else
-                       "BASELINE configs[2] shape: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",
-                       "queries": Q, "bank": N,
-                       "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d (%s), queries replicated, "
-                       "all-reduce(min) of %d packed keys" % (world, shard_note, Q) if world > 1 else "single GPU",
-                       "shard_rows": [int(bounds[r + 1] - bounds[r]) for r in range(world)]},
-            "roofline": roofline,
-            "cpu_baseline": cpu,
-            "kernels": kernels,
-            "phases_ms_per_step_rank0": {k: round(v / args.steps, 3) for k, v in phases.items()},
-            "parity": parity,
-            "auroc": auroc,
-            "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
-        }
+    if rank != 0:
+        return None
+    line = {
+        "metric": "attack query-images/sec (10k queries x 100k samples) + AUROC delta vs ref",
+        "value": round(value, 2), "unit": "query-images/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": (("split-f16 (hi+lo, f32 accumulate; generator)" if split else "f32 (generator)") + " + i8->i32 exact (distance)") if lp_model is None
+        else ("split-f16" if split else "f32") + " (generator, VGG16) + " + ("f16 search rows" if args.feat_rows == "fp16" else "split-f16") + " (LPIPS contraction)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: DCGAN-64 generator -> 8-bit bank, L2 1-NN (fbb)" if lp_model is None else
+                   "BASELINE configs[2]: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",
+                   "queries": Q, "bank": N,
+                   "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d (%s), queries replicated, "
+                   "all-reduce(min) of %d packed keys (%s)" % (world, shard_note, Q, {"native": "RCCL through the C ABI on the library's stream",
+                                                                                    "torch": "torch.distributed nccl", "gloo": "gloo through host memory"}.get(job.collective, ""))
+                   if world > 1 else "single GPU",
+                   "shard_rows": [int(bounds[r + 1] - bounds[r]) for r in range(world)]},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "kernels": kernels,
+        "phases_ms_per_step_rank0": {k: round(v / steps, 3) for k, v in phases.items()},
+        "parity": parity,
+        "auroc": auroc,
+        "speedup_vs_cpu_baseline": round(value / cpu["value"], 1) if cpu else None,
+    }
+    return line
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--bank", type=int, default=100000)
+    ap.add_argument("--batch-size", type=int, default=64)
+    ap.add_argument("--chunk", type=int, default=0, help="generator images per pass (0 = library default)")
+    ap.add_argument("--cpu-queries", type=int, default=128, help="queries timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch CPU threads for the baseline (0 = min(16, usable cores))")
+    ap.add_argument("--check-queries", type=int, default=64, help="queries checked against the oracle after the run")
+    ap.add_argument("--gen-precision", type=int, default=1, choices=[0, 1],
+                    help="generator arithmetic: 1 = split-fp16 (three fp16 MFMAs per product, default), 0 = fp32 MFMA")
+    ap.add_argument("--collective", default="native", choices=["native", "torch", "gloo"],
+                    help="N > 1, the key reduction: native = RCCL through the C ABI (gl_allreduce_min_keys, default; falls back to torch if the "
+                         "communicator cannot be formed), torch = torch.distributed's nccl backend, gloo = through host memory (rehearsal: ranks may share a GPU)")
+    ap.add_argument("--backend", default=None, help="deprecated alias: nccl -> --collective torch, gloo -> --collective gloo")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: equal bank shards instead of shards sized by each rank's measured generator speed")
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="stop the CPU baseline after this many seconds (at least 8 queries are timed)")
+    ap.add_argument("--feat-rows", default="fp16", choices=["fp16", "split"],
+                    help="l2-lpips only: rows of the nearest-neighbour search: fp16 = one half per LPIPS value (gl_feat_knn_h1, default), "
+                         "split = hi + lo halves of everything (gl_feat_knn)")
+    ap.add_argument("--distance", default="l2", choices=["l2", "l2-lpips"],
+                    help="l2 = BASELINE configs[1] (default, the headline); l2-lpips = configs[2] (0.2*LPIPS+L2; needs ~2 MB of HBM per image)")
+    ap.add_argument("--secondary", default="auto", choices=["auto", "on", "off"],
+                    help="the two further measurements (configs[2] under 0.2*LPIPS+L2, and the fp32-MFMA generator): auto = with the default one-GPU "
+                         "headline workload only")
+    ap.add_argument("--secondary-steps", type=int, default=2)
+    args = ap.parse_args()
+    if args.backend == "nccl":
+        args.collective = "torch"
+    elif args.backend == "gloo":
+        args.collective = "gloo"
+
+    job = setup_job(args)
+    line = measure(job, args, args.distance, args.gen_precision, args.steps, args.warmup, cpu_leg=True, headline=True)
+    default_run = job.world == 1 and args.distance == "l2" and args.gen_precision == 1 and (
+        args.secondary == "on" or (args.secondary == "auto" and args.queries == 10000 and args.bank == 100000))
+    if default_run:
+        import gc
+        gc.collect()
+        sec = measure(job, args, "l2-lpips", 1, args.secondary_steps, 1, cpu_leg=True, headline=False)
+        gc.collect()
+        f32 = measure(job, args, "l2", 0, 3, 1, cpu_leg=False, headline=False)
+        keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "kernels", "phases_ms_per_step_rank0",
+                "parity", "auroc", "speedup_vs_cpu_baseline")
+        line["secondary"] = {k: sec[k] for k in keep}
+        line["secondary_fp32"] = {k: f32[k] for k in keep if k != "cpu_baseline" and k != "speedup_vs_cpu_baseline"}
+    if job.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if job.world > 1:
+        job.dist.barrier()
+        if job.comm is not None:
+            job.comm.destroy()
+        job.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

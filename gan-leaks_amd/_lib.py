@@ -19,6 +19,8 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "ganleaks.h")
 
 GL_OK = 0
 GL_ERR_EMPTY_BANK = -5
+GL_ERR_RCCL = -6
+GL_COMM_ID_BYTES = 128
 
 
 class GanLeaksError(RuntimeError):
@@ -119,6 +121,14 @@ SIGNATURES = {
     "gl_lpips_search_features_f32": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
     "gl_feat_knn_h1": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
     "gl_feat_rows_dist": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
+    "gl_comm_unique_id": (_i, [_p]),
+    "gl_comm_init_rank": (_i, [_p, _p, _i, _i, _pp]),
+    "gl_comm_init_all": (_i, [_pp, _i, _pp]),
+    "gl_comm_destroy": (_i, [_p]),
+    "gl_comm_rank": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "gl_allreduce_min_keys": (_i, [_p, _p, _i64]),
+    "gl_comm_group_start": (_i, []),
+    "gl_comm_group_end": (_i, []),
 }
 
 _lib = None
@@ -205,6 +215,15 @@ class Context:
     def sync(self):
         check(self.lib.gl_ctx_sync(self.handle))
 
+    def destroy(self):
+        """release the stream and scratch of a context created with Context(device) (arrays and models built on it must be gone)"""
+        if getattr(self, "handle", None) is not None:
+            for k, v in list(Context._instances.items()):
+                if v is self:
+                    del Context._instances[k]
+            self.lib.gl_ctx_destroy(self.handle)
+            self.handle = None
+
     def h3_saturations(self):
         """workgroups of split-fp16 kernels that clamped a value to the fp16 range since the last call (synchronises)"""
         n = _i64(0)
@@ -256,6 +275,65 @@ class Context:
             check(self.lib.gl_prof_read(self.handle, tag, ctypes.byref(ms), ctypes.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+
+class Comm:
+    """one rank of an RCCL communicator bound to a Context (gl_comm): the cross-GPU minimum of the packed keys.
+
+    Comm.unique_id() on rank 0 -> bytes carried to every rank by the launcher -> Comm(ctx, id, rank, nranks) on every rank (collective),
+    or Comm.init_all([ctx0, ctx1, ...]) for one process driving several GPUs."""
+
+    def __init__(self, ctx, unique_id=None, rank=0, nranks=1, _handle=None):
+        self.ctx = ctx
+        if _handle is not None:
+            self.handle = _handle
+        else:
+            if unique_id is None:
+                if nranks != 1:
+                    raise ValueError("a communicator of %d ranks needs the unique id rank 0 generated" % nranks)
+                unique_id = Comm.unique_id()
+            if len(unique_id) != GL_COMM_ID_BYTES:
+                raise ValueError("unique id must be %d bytes" % GL_COMM_ID_BYTES)
+            buf = ctypes.create_string_buffer(bytes(unique_id), GL_COMM_ID_BYTES)
+            h = _p()
+            check(ctx.lib.gl_comm_init_rank(ctx.handle, buf, int(rank), int(nranks), ctypes.byref(h)))
+            self.handle = h
+        r, n = _i(0), _i(0)
+        check(ctx.lib.gl_comm_rank(self.handle, ctypes.byref(r), ctypes.byref(n)))
+        self.rank, self.nranks = r.value, n.value
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(GL_COMM_ID_BYTES)
+        check(load().gl_comm_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def init_all(cls, contexts):
+        n = len(contexts)
+        arr = (_p * n)(*[c.handle for c in contexts])
+        out = (_p * n)()
+        check(load().gl_comm_init_all(arr, n, out))
+        return [cls(contexts[i], _handle=_p(out[i])) for i in range(n)]
+
+    def allreduce_min_keys(self, keys):
+        """in place on the context's stream (asynchronous): keys[q] = min over ranks"""
+        if keys.dtype != np.dtype(np.uint64):
+            raise TypeError("keys must be uint64")
+        n = int(np.prod(keys.shape, dtype=np.int64))
+        check(self.ctx.lib.gl_allreduce_min_keys(self.handle, _p(keys.ptr), n))
+        return keys
+
+    def destroy(self):
+        if getattr(self, "handle", None) is not None:
+            self.ctx.lib.gl_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 class Event:

@@ -38,3 +38,19 @@ def test_bench_line_l2_lpips():
     d = _run("--distance", "l2-lpips", "--steps", "1", "--warmup", "1", "--queries", "256", "--bank", "1024", "--cpu-queries", "0")
     assert d["roofline"]["bound"] == "mfma" and d["cpu_baseline"] is None and d["parity"]["idx_equal"] is True
     assert d["parity"]["max_abs_dist_err"] < 1e-5
+
+
+def test_bench_line_with_secondary_measurements():
+    """what the driver's default run prints, at a reduced size: the headline line plus `secondary` (configs[2]: 0.2*LPIPS+L2, own roofline, parity and
+    cpu_baseline) and `secondary_fp32` (generator with fp32 MFMA products)"""
+    d = _run("--steps", "2", "--warmup", "1", "--queries", "512", "--bank", "4096", "--cpu-queries", "8", "--cpu-seconds", "4", "--secondary", "on")
+    assert d["roofline"]["kernel"] == "gather_conv" and d["cpu_baseline"]["kind"] == "port"
+    s = d["secondary"]
+    assert "configs[2]" in s["config"]["workload"] and s["roofline"]["kernel"] == "feat_knn" and s["roofline"]["bound"] == "mfma"
+    assert abs(s["roofline"]["frac"] - s["roofline"]["achieved"] / s["roofline"]["peak"]) < 1e-3
+    assert s["parity"]["idx_equal"] is True and s["parity"]["max_abs_dist_err"] < 1e-5
+    c = s["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["max_abs_loss_diff_vs_gpu"] < 1e-5 and "pairs" in c["sample"]
+    f = d["secondary_fp32"]
+    assert f["dtype"].startswith("f32") and f["roofline"]["peak"] == 157.3 and f["parity"]["idx_equal"] is True
+    assert f["ms_per_step"] > 0 and "cpu_baseline" not in f

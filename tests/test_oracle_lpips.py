@@ -46,3 +46,20 @@ def test_lpips_oracle_matches_reference_at_config3_size(name, synth, oracle, gol
     np.testing.assert_allclose(d.astype(np.float64), g["dist"], atol=2e-6)
     lp = lpips_oracle.lpips_matrix(sd, lin, q, bank)
     np.testing.assert_allclose(lp, g["lpips"], atol=2e-6)
+
+
+def test_torch_port_l2_lpips_matches_reference(synth, oracle, golden_dir):
+    """oracle/torch_port.py's fp32 restatement of Loss('l2-lpips').forward (the timed CPU baseline of bench.py's l2-lpips line) against the
+    reference's PNetLin + custom_knn vectors"""
+    import torch
+    import torch_port
+    g = np.load(os.path.join(golden_dir, "lpips_res32.npz"))
+    lin = np.load(os.path.join(golden_dir, "lpips_lin_v0.1.npz"))
+    loss = torch_port.make_l2_lpips_loss(synth.vgg16_state_dict(int(g["vgg_seed"])), [lin["lin%d" % i] for i in range(5)])
+    case = synth.attack_case(int(g["seed"]), int(g["n_bank"]), int(g["n_pos"]), int(g["n_neg"]), int(g["res"]), sigma=20.0)
+    bank = torch_port.dequantize(case["bank"])
+    q = torch_port.dequantize(np.concatenate([case["pos"], case["neg"]]))
+    bs = int(g["batch_size"])
+    for k in (0, 3, 7):
+        d, i = torch_port.custom_knn(bank, q[k], loss, bs)
+        assert i == int(g["idx"][k]) and abs(d - float(g["dist"][k])) < 1e-6

@@ -88,3 +88,36 @@ def test_weighted_bounds():
     for bad in ([], [1, 0], [1, float("nan")]):
         with pytest.raises(ValueError):
             shard.weighted_bounds(100, bad)
+
+
+def test_host_merge_survives_repeated_calls_with_skewed_threads():
+    """shard.HostMerge (the in-process fallback of attack_on_devices): 3 threads, 40 merges in a row, every thread sleeping at a different point
+    -- a fast rank's next deposit must not replace what a slow rank is still merging (one rendezvous was not enough)"""
+    import threading
+    import time
+    import ganleaks_amd  # noqa: F401
+    from ganleaks_amd import shard
+    world, rounds, nq = 3, 40, 257
+    rng = np.random.default_rng(3)
+    data = rng.integers(0, 2 ** 62, size=(rounds, world, nq), dtype=np.uint64)
+    hm = shard.HostMerge(world)
+    out = [[None] * rounds for _ in range(world)]
+
+    def work(rank):
+        for r in range(rounds):
+            if (r + rank) % 3 == 0:
+                time.sleep(0.002)                      # late to deposit
+            m = hm.merge(rank, data[r, rank])
+            if (r + rank) % 3 == 1:
+                time.sleep(0.002)                      # slow to use the result while the others race ahead
+            out[rank][r] = m.copy()
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for r in range(rounds):
+        want = data[r].min(axis=0)
+        for rank in range(world):
+            assert np.array_equal(out[rank][r], want), (r, rank)
