@@ -425,7 +425,9 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
             cpu_s = time.perf_counter() - tc
             pairs_s = 64 * nb / cpu_s
             from ganleaks_amd.attack_models.utils import Loss
-            dev_loss = Loss("l2-lpips", lpips=lp_model)
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):              # Loss announces its distance on stdout like the reference (utils.py:166)
+                dev_loss = Loss("l2-lpips", lpips=lp_model)
             dv = np.concatenate([np.asarray(dev_loss(host_bank[64 * b:64 * (b + 1)], queries_u8[:1])) for b in range(nb)])
             cpu = {"value": round(pairs_s / n_eff, 8), "unit": "query-images/s", "cores": int(torch.get_num_threads()), "kind": "port",
                    "sample": "%d batches of 64 (bank image, query) pairs under 0.2*LPIPS+L2, autograd on as in the reference, PyTorch-CPU restatement of "
