@@ -43,6 +43,10 @@ struct GlGatherConv {
     float *tail_out;
     int64_t tail_ld;
     float tail_scale;
+    // gather_conv_h3 only, optional (out_mode 2, all `cols` channels inside one tile -- gl_conv_h3_tile_channels() says how many that is):
+    // PGGAN's PixelNorm (gan_models/pggan/model_torch.py:25-31) applied to the activated outputs before they are stored,
+    // v -> v / sqrt(mean_c v^2 / A^2 + 1e-8) with A = pixnorm_act the factor the stored activations carry; 0 = off
+    float pixnorm_act;
 };
 
 // host: rows [48][channels] (channels = 64 or 128) of fp32 tail weights (row = GEMM column) -> the operand image the fused epilogue reads
@@ -57,6 +61,8 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 
 // split-fp16 variant (gl_conv_h3.hip): `in` and `wpack` are in the split layout (see that file); same parameter block
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p, int phases);
+// output channels one workgroup tile of gl_launch_gather_conv_h3 will cover for this problem (the fused PixelNorm needs cols <= that)
+int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases);
 // fp32 rows [n][d] -> split layout [n][dpad/32][128 B] of (value * scale)
 int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out);
 // host: packed fp32 weight rows [rows][K] -> split layout of (value * scale); `out` holds rows * K * 4 bytes

@@ -31,6 +31,8 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 //   <2,2,4,4>: 128 channels x 128 positions, 4 waves of 64 x 64, 64 KiB LDS (2 workgroups per CU)
 //   <1,4,4,4>: 64 channels x 256 positions, 4 waves, 80 KiB LDS (2 workgroups per CU): layers with <= 64 output columns
 //   <2,4,8,4>: 256 channels x 256 positions, 8 waves of 128 x 64, 128 KiB LDS (1 workgroup per CU): wide layers of large passes
+//   <1,8,8,4>: 128 channels x 512 positions, 8 waves of 128 x 64, 160 KiB LDS: 65..128-column layers of large passes (PGGAN at 128 x 128,
+//              VGG16 conv2_x): +4.5 % on PGGAN-256 over <2,2,4,4> (A/B alternating on one device)
 // K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): a 128 x 256
 // tile with 8 waves of 64 x 64, 256 x 256 with 4 waves of 128 x 128 (1 wave per SIMD), 128 x 512 / 128 x 256 tiles for 128-column
 // layers, a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU, staggered staging of the two wave halves,
@@ -261,6 +263,57 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                 }
         }
     } else {
+    // fused PixelNorm: all channels of a position sit in this workgroup (host-checked: cols <= HTC).  Pass 1 activates in place and sums the
+    // squares per position -- over the lane's channels, the 4 lane groups (2 shuffles) and the WC channel waves (LDS); pass 2 below stores v * inv.
+    const bool pixnorm = p.pixnorm_act > 0.0f;
+    float pinv[TP];
+#pragma unroll
+    for (int j = 0; j < TP; ++j) pinv[j] = 1.0f;
+    if (pixnorm) {
+        float ss[TP];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) ss[j] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;
+            const bool real = ch < p.cols;
+            float sc[4], sh[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = real ? p.scale[(ch + r) % p.cmod] : 0.0f; sh[r] = real ? p.shift[(ch + r) % p.cmod] : 0.0f; }
+#pragma unroll
+            for (int j = 0; j < TP; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = fmaf(acc[i][j][r], sc[r], sh[r]);
+                    t = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
+                    acc[i][j][r] = t;
+                    ss[j] = fmaf(t, t, ss[j]);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            ss[j] += __shfl_xor(ss[j], 16, 64);
+            ss[j] += __shfl_xor(ss[j], 32, 64);
+        }
+        if constexpr (WC > 1) {
+            float *xs = reinterpret_cast<float *>(smem + 8192);          // [WC][WP][TP][16]
+            if (fk == 0) {
+#pragma unroll
+                for (int j = 0; j < TP; ++j) xs[((wc * WP + wp_) * TP + j) * 16 + frow] = ss[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                float t = 0.0f;
+#pragma unroll
+                for (int w2 = 0; w2 < WC; ++w2) t += xs[((w2 * WP + wp_) * TP + j) * 16 + frow];
+                ss[j] = t;
+            }
+        }
+        const float A = p.pixnorm_act;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) pinv[j] = A / sqrtf(ss[j] / (float)p.cols + 1e-8f * A * A);
+    }
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;     // first of this lane's 4 consecutive channels
@@ -275,8 +328,12 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float t = fmaf(acc[i][j][r], sc[r], sh[r]);
-                v[r] = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
+                if (pixnorm) {
+                    v[r] = acc[i][j][r] * pinv[j];
+                } else {
+                    float t = fmaf(acc[i][j][r], sc[r], sh[r]);
+                    v[r] = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
+                }
             }
             if (p.out_mode == 2) {
                 // split layout: [o][cols/32][hi 32 | lo 32] halves
@@ -338,6 +395,30 @@ static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
     return GL_OK;
 }
 
+// which tile gl_launch_gather_conv_h3 picks: 0 = <2,2> 128 x 128, 1 = <1,4> 64 channels x 256 positions, 2 = <2,4,8,4> 256 x 256,
+// 3 / 4 = the fused-tail forms of 0 / 1
+static int h3_tile_choice(const GlGatherConv &p, int phases)
+{
+    if (p.tail_w) return p.cols == 128 ? 3 : 4;
+    // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
+    // (64 channels x 512 positions with 8 waves measured 2 % slower on PGGAN-256 than this tile at two workgroups per CU)
+    if (p.cols <= 64) return 1;
+    // wide layers with enough work to fill the chip: 256 channels x 256 positions, 8 waves of 128 x 64 (24 LDS fragment reads per 96
+    // MFMAs instead of 16 per 48, half the staging per MFMA): +7 % on the DCGAN stack (A/B on one device, profiles/r01/README.md)
+    if (p.cols % 256 == 0 && gl_ceil_div(p.positions, 256) * (p.cols / 256) * phases >= 256) return 2;
+    // 65..128 columns with many positions (PGGAN's 128-channel block at 128 x 128): 128 channels x 512 positions, 8 waves of 128 x 64 like the
+    // wide tile's, all 160 KiB of LDS
+    static const int wide128 = getenv("GL_H3_TILE128") ? atoi(getenv("GL_H3_TILE128")) : 1;
+    if (wide128 && p.cols <= 128 && gl_ceil_div(p.positions, 512) * phases >= 512) return 5;
+    return 0;
+}
+
+int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases)
+{
+    const int t = h3_tile_choice(p, phases);
+    return t == 2 ? 256 : (t == 1 || t == 4) ? 64 : 128;       // tiles 0, 3 and 5 hold 128 channels
+}
+
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
     gl_make_current(ctx);
@@ -359,16 +440,18 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE((uint64_t)p.cols_pad * p.ntaps * p.Cin * 4ull < 0xC0000000ull, "gather_conv_h3: packed weights too large");
     if (p.positions == 0) return GL_OK;
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
-    // narrow outputs (the generator's 48-column RGB tail, toRGB): 64 channels x 256 positions, half the padded MFMAs of the square tile
-    if (p.tail_w) {
+    GL_REQUIRE(p.pixnorm_act == 0.0f || (p.out_mode == 2 && !p.tail_w && phases == 1 && p.cols <= gl_conv_h3_tile_channels(p, phases)),
+               "gather_conv_h3: the fused PixelNorm needs split output and all %d channels in one tile", p.cols);
+    if (p.tail_w)
         GL_REQUIRE((p.cols == 128 || p.cols == 64) && p.cmod == p.cols && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 64- or 128-channel layer");
-        return p.cols == 128 ? launch_h3<2, 2, 4, 4, true>(ctx, p, phases) : launch_h3<1, 4, 4, 4, true>(ctx, p, phases);
+    switch (h3_tile_choice(p, phases)) {
+    case 3: return launch_h3<2, 2, 4, 4, true>(ctx, p, phases);
+    case 4: return launch_h3<1, 4, 4, 4, true>(ctx, p, phases);
+    case 1: return launch_h3<1, 4>(ctx, p, phases);
+    case 2: return launch_h3<2, 4, 8, 4>(ctx, p, phases);
+    case 5: return launch_h3<1, 8, 8, 4>(ctx, p, phases);
+    default: return launch_h3<2, 2>(ctx, p, phases);
     }
-    if (p.cols <= 64) return launch_h3<1, 4>(ctx, p, phases);
-    // wide layers with enough work to fill the chip: 256 channels x 256 positions, 8 waves of 128 x 64 (24 LDS fragment reads per 96
-    // MFMAs instead of 16 per 48, half the staging per MFMA): +7 % on the DCGAN stack (A/B on one device, profiles/r01/README.md)
-    if (p.cols % 256 == 0 && gl_ceil_div(p.positions, 256) * (p.cols / 256) * phases >= 256) return launch_h3<2, 4, 8, 4>(ctx, p, phases);
-    return launch_h3<2, 2>(ctx, p, phases);
 }
 
 int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out)

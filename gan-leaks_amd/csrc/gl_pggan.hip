@@ -213,9 +213,12 @@ int pg_make_h3(gl_pggan *g, void *h3_slot, const std::vector<float> &pk, size_t 
     return rc;
 }
 
+// pixnorm: the layer is followed by PixelNorm.  In split-fp16 mode it is applied in the convolution's epilogue whenever one tile holds all
+// output channels (everything up to 256 channels); *pixnorm_done says whether it was.
 int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int Cin, const float *w, const float *bias, int cols, int ntaps, int act,
-            float *out, const gl_pggan::H3 *h3 = nullptr, bool rgb = false)
+            float *out, const gl_pggan::H3 *h3 = nullptr, bool rgb = false, bool *pixnorm_done = nullptr)
 {
+    if (pixnorm_done) *pixnorm_done = false;
     GlGatherConv p = {};
     p.in = in; p.positions = m * H * W; p.H = H; p.W = W; p.Cin = Cin; p.up = up;
     p.wpack = w; p.cols = cols; p.cols_pad = cols_pad_of(cols); p.ntaps = ntaps;
@@ -232,6 +235,10 @@ int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int C
         if (rgb) { p.cols = 4; p.cmod = 4; p.out_mode = 0; }      // 3 real + 1 padding column, fp32 [pos][4]
         else p.out_mode = 2;
         p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128;
+        if (pixnorm_done && !rgb && p.cols <= gl_conv_h3_tile_channels(p, 1)) {
+            p.pixnorm_act = kPgAct;
+            *pixnorm_done = true;
+        }
         return gl_launch_gather_conv_h3(g->ctx, p, 1);
     }
     return gl_launch_gather_conv(g->ctx, p, 1);
@@ -461,18 +468,19 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
             }
             if (rc != GL_OK) return rc;
         }
-        rc = pg_conv(g, g->ws_buf[0], m, 4, 4, 0, C, g->w_i3, g->b_i3, C, 9, 2, g->ws_buf[1], &g->h_i3);
+        bool normed = false;
+        rc = pg_conv(g, g->ws_buf[0], m, 4, 4, 0, C, g->w_i3, g->b_i3, C, 9, 2, g->ws_buf[1], &g->h_i3, false, &normed);
         if (rc != GL_OK) return rc;
-        rc = pg_pixelnorm(g, g->ws_buf[1], m * 16, C);
+        if (!normed) rc = pg_pixelnorm(g, g->ws_buf[1], m * 16, C);
         if (rc != GL_OK) return rc;
         int cur = 1, prev = 1, hw = 4;
         for (int s = 0; s < steps; ++s) {
             hw *= 2;
             const int b1 = (cur + 1) % 3, b2 = (cur + 2) % 3;
-            rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 1, g->cin[s], g->w_blk[s][0], g->b_blk[s][0], g->cout[s], 9, 2, g->ws_buf[b1], &g->h_blk[s][0]);
-            if (rc == GL_OK) rc = pg_pixelnorm(g, g->ws_buf[b1], m * hw * hw, g->cout[s]);
-            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2], &g->h_blk[s][1]);
-            if (rc == GL_OK) rc = pg_pixelnorm(g, g->ws_buf[b2], m * hw * hw, g->cout[s]);
+            rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 1, g->cin[s], g->w_blk[s][0], g->b_blk[s][0], g->cout[s], 9, 2, g->ws_buf[b1], &g->h_blk[s][0], false, &normed);
+            if (rc == GL_OK && !normed) rc = pg_pixelnorm(g, g->ws_buf[b1], m * hw * hw, g->cout[s]);
+            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2], &g->h_blk[s][1], false, &normed);
+            if (rc == GL_OK && !normed) rc = pg_pixelnorm(g, g->ws_buf[b2], m * hw * hw, g->cout[s]);
             if (rc != GL_OK) return rc;
             prev = cur;      // input of this block (low resolution): `upscaled` of the reference is its x2 view
             cur = b2;
