@@ -263,64 +263,95 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                 }
         }
     } else {
-    // fused PixelNorm: all channels of a position sit in this workgroup (host-checked: cols <= HTC).  Pass 1 activates in place and sums the
-    // squares per position -- over the lane's channels, the 4 lane groups (2 shuffles) and the WC channel waves (LDS); pass 2 below stores v * inv.
+    // fused PixelNorm: all channels of a position sit in this workgroup (host-checked: cols <= HTC).  Pass 1 activates in place, rounds every
+    // value to what the split layout holds (hi + lo) and sums the squares per position in ONE canonical order -- per 16-channel tile: the
+    // lane's 4 channels as an fmaf chain, then (g0 + g1) + (g2 + g3) over the 4 lane groups; then a balanced binary tree over the tiles --
+    // which pixelnorm_split_kernel (gl_pggan.hip) reproduces on stored values: fused or not, and whatever the tile shape, the stored
+    // activations are bit-identical (a pass of another size may pick another tile).  Pass 2 below stores v * inv.
     const bool pixnorm = p.pixnorm_act > 0.0f;
     float pinv[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) pinv[j] = 1.0f;
     if (pixnorm) {
-        float ss[TP];
-#pragma unroll
-        for (int j = 0; j < TP; ++j) ss[j] = 0.0f;
+        float tss[TC][TP];
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;
             const bool real = ch < p.cols;
+            const int chm = ch < p.cmod ? ch : ch % p.cmod;     // ch and cmod are multiples of 4: (ch + r) % cmod = chm + r
             float sc[4], sh[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = real ? p.scale[(ch + r) % p.cmod] : 0.0f; sh[r] = real ? p.shift[(ch + r) % p.cmod] : 0.0f; }
+            for (int r = 0; r < 4; ++r) { sc[r] = real ? p.scale[chm + r] : 0.0f; sh[r] = real ? p.shift[chm + r] : 0.0f; }
 #pragma unroll
-            for (int j = 0; j < TP; ++j)
+            for (int j = 0; j < TP; ++j) {
+                float s1 = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = fmaf(acc[i][j][r], sc[r], sh[r]);
                     t = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
-                    acc[i][j][r] = t;
-                    ss[j] = fmaf(t, t, ss[j]);
+                    const float c = fminf(fmaxf(t, -65504.0f), 65504.0f);
+                    saturated |= (c != t) && (o4[j] >= 0);
+                    const _Float16 h = (_Float16)c;
+                    const float vq = __fadd_rn((float)h, (float)(_Float16)__fsub_rn(c, (float)h));
+                    acc[i][j][r] = vq;
+                    s1 = fmaf(vq, vq, s1);
                 }
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                tss[i][j] = s1;
+            }
         }
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            ss[j] += __shfl_xor(ss[j], 16, 64);
-            ss[j] += __shfl_xor(ss[j], 32, 64);
-        }
+        // the (up to 16) tile sums of a position are combined as a balanced binary tree over the tile index, absent tiles counting 0
+        float ss[TP];
+        constexpr int NT = WC * TC;                                      // tiles of 16 channels in the workgroup tile (4, 8 or 16)
+        static_assert(NT == 4 || NT == 8 || NT == 16, "fused PixelNorm: 4, 8 or 16 channel tiles");
         if constexpr (WC > 1) {
-            float *xs = reinterpret_cast<float *>(smem + 8192);          // [WC][WP][TP][16]
+            float *xs = reinterpret_cast<float *>(smem + 8192);          // [WC * TC][WP][TP][16]
             if (fk == 0) {
 #pragma unroll
-                for (int j = 0; j < TP; ++j) xs[((wc * WP + wp_) * TP + j) * 16 + frow] = ss[j];
+                for (int i = 0; i < TC; ++i)
+#pragma unroll
+                    for (int j = 0; j < TP; ++j) xs[(((wc * TC + i) * WP + wp_) * TP + j) * 16 + frow] = tss[i][j];
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                float t = 0.0f;
+                float t[NT];
 #pragma unroll
-                for (int w2 = 0; w2 < WC; ++w2) t += xs[((w2 * WP + wp_) * TP + j) * 16 + frow];
-                ss[j] = t;
+                for (int gt = 0; gt < NT; ++gt) t[gt] = xs[((gt * WP + wp_) * TP + j) * 16 + frow];
+#pragma unroll
+                for (int w = 1; w < NT; w *= 2)
+#pragma unroll
+                    for (int k = 0; k < NT; k += 2 * w) t[k] = __fadd_rn(t[k], t[k + w]);
+                ss[j] = t[0];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                float t[NT];
+#pragma unroll
+                for (int gt = 0; gt < NT; ++gt) t[gt] = tss[gt][j];
+#pragma unroll
+                for (int w = 1; w < NT; w *= 2)
+#pragma unroll
+                    for (int k = 0; k < NT; k += 2 * w) t[k] = __fadd_rn(t[k], t[k + w]);
+                ss[j] = t[0];
             }
         }
         const float A = p.pixnorm_act;
 #pragma unroll
-        for (int j = 0; j < TP; ++j) pinv[j] = A / sqrtf(ss[j] / (float)p.cols + 1e-8f * A * A);
+        for (int j = 0; j < TP; ++j) pinv[j] = __fdiv_rn(A, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss[j], (float)p.cols), __fmul_rn(__fmul_rn(1e-8f, A), A))));
     }
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;     // first of this lane's 4 consecutive channels
         if (ch >= p.cols) continue;                             // cols is a multiple of 4 (host-checked)
-        float sc[4], sh[4];
+        float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!pixnorm) {
+            const int chm = ch < p.cmod ? ch : ch % p.cmod;     // ch and cmod are multiples of 4: (ch + r) % cmod = chm + r
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { sc[r] = p.scale[(ch + r) % p.cmod]; sh[r] = p.shift[(ch + r) % p.cmod]; }
+            for (int r = 0; r < 4; ++r) { sc[r] = p.scale[chm + r]; sh[r] = p.shift[chm + r]; }
+        }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int o = o4[j];
@@ -329,7 +360,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (pixnorm) {
-                    v[r] = acc[i][j][r] * pinv[j];
+                    v[r] = __fmul_rn(acc[i][j][r], pinv[j]);
                 } else {
                     float t = fmaf(acc[i][j][r], sc[r], sh[r]);
                     v[r] = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
@@ -344,7 +375,8 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                     const float c = fminf(fmaxf(v[r], -65504.0f), 65504.0f);
                     saturated |= (c != v[r]);
                     hi[r] = (_Float16)c;
-                    lo[r] = (_Float16)(c - (float)hi[r]);
+                    // after the fused PixelNorm the low half is the exact residual of the product (one fma), as pixelnorm_split_kernel computes it
+                    lo[r] = pixnorm ? (_Float16)fmaf(acc[i][j][r], pinv[j], -(float)hi[r]) : (_Float16)__fsub_rn(c, (float)hi[r]);
                 }
                 *reinterpret_cast<v4h *>(dst) = hi;
                 *reinterpret_cast<v4h *>(dst + 64) = lo;
@@ -425,6 +457,7 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GlGatherConv p = p_in;
     p.sat_flag = ctx->h3_sat;
     GL_REQUIRE(p.Cin % 32 == 0, "gather_conv_h3: Cin=%d must be a multiple of 32", p.Cin);
+    GL_REQUIRE(p.cmod > 0 && p.cmod % 4 == 0, "gather_conv_h3: cmod=%d must be a positive multiple of 4", p.cmod);
     GL_REQUIRE(p.cols_pad % 128 == 0 && p.cols <= p.cols_pad && p.cols % 4 == 0, "gather_conv_h3: cols=%d / cols_pad=%d (multiple of 128)", p.cols, p.cols_pad);
     GL_REQUIRE(phases >= 1 && phases <= 4 && p.ntaps >= 1 && p.ntaps <= 16, "gather_conv_h3: bad phases/taps");
     GL_REQUIRE(p.act >= 0 && p.act <= 2 && !p.residual, "gather_conv_h3: activation %d / residual not supported", p.act);

@@ -7,6 +7,7 @@
 // Every convolution runs in gather_conv_kernel (fp32 MFMA): 3x3 = 9 taps, the nearest-neighbour upsampling
 // is fused into the gather (GlGatherConv::up), toRGB = 1 tap with 3 (padded to 64) columns.
 #include "gl_conv.h"
+#include <cstdlib>
 #include <cmath>
 #include <vector>
 
@@ -54,34 +55,45 @@ __global__ void __launch_bounds__(256) pixelnorm_rows_split_kernel(const float *
     }
 }
 
-// in place on the split layout: stored v = A x  ->  A x / sqrt(mean x^2 + eps) = A v / sqrt(mean v^2 + eps A^2); C % 64 == 0 or C == 32
+// in place on the split layout: stored v = A x  ->  A x / sqrt(mean x^2 + eps) = A v / sqrt(mean v^2 + eps A^2); C % 16 == 0.
+// One wave per position.  The sum of squares follows the canonical order of the fused form in gather_conv_h3_kernel's epilogue (per 16-channel
+// tile: 4 channels per lane as an fmaf chain, then (g0 + g1) + (g2 + g3); a balanced binary tree over the 16 tiles of every 256 channels;
+// the 256-channel groups in ascending order) and every product / sum is individually rounded, so a layer gives the same bits whether
+// its PixelNorm ran fused or here.
 __global__ void __launch_bounds__(256) pixelnorm_split_kernel(char *__restrict__ x, int64_t positions, int C)
 {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t pos = wave; pos < positions; pos += nwaves) {
         char *p = x + pos * C * 4;
         float ss = 0.0f;
-        for (int c = 2 * lane; c < C; c += 128) {
-            const char *q = p + (c >> 5) * 128 + (c & 31) * 2;
-            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
-            const float a = (float)hi[0] + (float)lo[0], b = (float)hi[1] + (float)lo[1];
-            ss = fmaf(a, a, ss); ss = fmaf(b, b, ss);
-        }
+        for (int c = 4 * lane; c - 4 * lane < C; c += 256) {   // 16 tiles (256 channels) per sweep: lane = tile * 4 + group
+            float s1 = 0.0f;
+            if (c < C) {
+                const char *q = p + (c >> 5) * 128 + (c & 31) * 2;
+                const h4 hi = *reinterpret_cast<const h4 *>(q), lo = *reinterpret_cast<const h4 *>(q + 64);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-        const float inv = kPgAct / sqrtf(ss / (float)C + 1e-8f * kPgAct * kPgAct);
-        for (int c = 2 * lane; c < C; c += 128) {
+                for (int r = 0; r < 4; ++r) { const float v = __fadd_rn((float)hi[r], (float)lo[r]); s1 = fmaf(v, v, s1); }
+            }
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) s1 = __fadd_rn(s1, __shfl_xor(s1, o, 64));
+            ss = c == 4 * lane ? s1 : __fadd_rn(ss, s1);
+        }
+        const float inv = __fdiv_rn(kPgAct, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss, (float)C), __fmul_rn(__fmul_rn(1e-8f, kPgAct), kPgAct))));
+        for (int c = 4 * lane; c < C; c += 256) {
             char *q = p + (c >> 5) * 128 + (c & 31) * 2;
-            const h2 hi = *reinterpret_cast<const h2 *>(q), lo = *reinterpret_cast<const h2 *>(q + 64);
-            const float a = ((float)hi[0] + (float)lo[0]) * inv, b = ((float)hi[1] + (float)lo[1]) * inv;
-            h2 nh, nl;
-            nh[0] = (_Float16)a; nh[1] = (_Float16)b;
-            nl[0] = (_Float16)(a - (float)nh[0]); nl[1] = (_Float16)(b - (float)nh[1]);
-            *reinterpret_cast<h2 *>(q) = nh;
-            *reinterpret_cast<h2 *>(q + 64) = nl;
+            const h4 hi = *reinterpret_cast<const h4 *>(q), lo = *reinterpret_cast<const h4 *>(q + 64);
+            h4 nh, nl;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = __fadd_rn((float)hi[r], (float)lo[r]);
+                nh[r] = (_Float16)__fmul_rn(v, inv);
+                nl[r] = (_Float16)fmaf(v, inv, -(float)nh[r]);          // the exact residual of the product, spelled out (the fused form does the same)
+            }
+            *reinterpret_cast<h4 *>(q) = nh;
+            *reinterpret_cast<h4 *>(q + 64) = nl;
         }
     }
 }
@@ -235,7 +247,8 @@ int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int C
         if (rgb) { p.cols = 4; p.cmod = 4; p.out_mode = 0; }      // 3 real + 1 padding column, fp32 [pos][4]
         else p.out_mode = 2;
         p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128;
-        if (pixnorm_done && !rgb && p.cols <= gl_conv_h3_tile_channels(p, 1)) {
+        static const int fuse = getenv("GL_PIXNORM_FUSE") ? atoi(getenv("GL_PIXNORM_FUSE")) : 1;      // 0: always the separate kernel (debugging)
+        if (fuse && pixnorm_done && !rgb && p.cols <= gl_conv_h3_tile_channels(p, 1)) {
             p.pixnorm_act = kPgAct;
             *pixnorm_done = true;
         }
