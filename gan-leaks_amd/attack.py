@@ -172,6 +172,17 @@ def _budget_bytes():
     return int(float(os.environ.get("GANLEAKS_CHUNK_GB", "64")) * (1 << 30))
 
 
+def _query_budget_bytes(chunk_bytes):
+    """HBM the prepared QUERY rows of a streamed l2-lpips attack may occupy next to one bank chunk ($GANLEAKS_QUERY_GB; default: 192 GiB of an
+    MI355X's 288 GB when the bank chunk has its default 64 GiB, the same as the chunk otherwise).  Query rows that fit stay resident for
+    the whole bank stream -- 10 000 search rows of 256 x 256 images are 160 GiB -- so the bank is generated and featurised once; rows that
+    do not fit go in slices, each against the whole (regenerated) bank stream."""
+    import os
+    if "GANLEAKS_QUERY_GB" in os.environ:
+        return int(float(os.environ["GANLEAKS_QUERY_GB"]) * (1 << 30))
+    return 192 * (1 << 30) if chunk_bytes == 64 * (1 << 30) else chunk_bytes
+
+
 def float_path(value=None):
     """how off-lattice fp32 rows are searched: 'exact' (default; VALU, one fixed fp32 order shared bit for bit with the oracle) or
     'mfma' (split-fp16 on the matrix cores, |y|^2 + |x|^2 - 2 y.x; distances agree to ~3e-6 * mean(x^2), 15-60x faster).  $GANLEAKS_FLOAT_PATH."""
@@ -255,7 +266,7 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
             # query rows that would not fit the budget either (256 x 256 images: 17 MB per search row) go in slices, each against
             # the whole bank stream -- the bank's features are then recomputed once per slice
             per_q = _feature_row_bytes(ctx, model, queries)
-            q_step = max(1, int(chunk_bytes // per_q))
+            q_step = max(1, int(_query_budget_bytes(chunk_bytes) // per_q))
             if len(queries) > q_step:
                 parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath)
                          for a in range(0, len(queries), q_step)]
@@ -263,6 +274,8 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
         fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=model.search_role("query"))
         b_role = "bank" if getattr(fq, "role", None) else None
         step = max(1, int(chunk_bytes // (fq.K * (2 if fq.role else 4))))
+        if fq.role:
+            step = _lp.preferred_bank_rows(step, fq.n)
         keys, buf = None, None
         for lo in range(0, n_rows, step):
             hi = min(lo + step, n_rows)
@@ -338,7 +351,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
             if distance == "l2-lpips" and len(bank):
                 per_img = _feature_row_bytes(ctx, model, bank)
                 if getattr(queries, "kind", None) != "feat" and len(queries) * per_img > chunk_bytes:
-                    need = chunk_bytes + 1           # the query rows alone exceed the budget: streamed form, queries in slices
+                    need = chunk_bytes + 1           # the query rows alone exceed a chunk: streamed form (queries resident or in slices)
                 else:
                     need = per_img * n_rows
             else:

@@ -425,6 +425,78 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
     }
 }
 
+// lpips_tap_split_kernel + maxpool2_split_kernel in one pass over the activation (taps relu1_2, 2_2, 3_3, 4_3 are each followed by a
+// 2x2 max-pool, pretrained_networks.py:108-115): a lane owns 8 channels of one 2 x 2 window, i.e. of 4 positions; per position the
+// same loads, the same sum of squares (same shuffle order) and the same V values as the tap kernel, plus max over the 4 positions
+// -> the pooled activation.  The activation (1 MB per image at relu1_2) is read once instead of twice.
+template <bool H1, int C>
+__global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *__restrict__ f, int64_t n, int H, int W, const float *__restrict__ coef,
+                                                                   char *__restrict__ V, int64_t ldv_bytes, int64_t off, char *__restrict__ pooled)
+{
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int G = C / 8;            // lanes per window
+    constexpr int P = 64 / G;           // windows per wave and pass
+    const int lane = threadIdx.x & 63;
+    const int cb = lane % G, pl = lane / G;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int Ho = H / 2, Wo = W / 2;
+    const int64_t HW = (int64_t)H * W, total = n * Ho * Wo;
+    float cf[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cf[j] = coef[cb * 8 + j];
+    const int in_off = (cb >> 2) * 128 + (cb & 3) * 16;          // hi halves of channels 8 cb .. 8 cb + 7 (lo: + 64)
+    for (int64_t w0 = wave * P; w0 < total; w0 += nwaves * P) {
+        const int64_t win = w0 + pl;
+        const bool live = win < total;
+        const int64_t im = live ? win / (Ho * Wo) : 0;
+        const int rem = live ? (int)(win - im * (Ho * Wo)) : 0;
+        const int yo = rem / Wo, xo = rem - yo * Wo;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = -__builtin_inff();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t pin = (int64_t)(2 * yo + (q >> 1)) * W + 2 * xo + (q & 1);      // position inside the image
+            float v[8];
+            float ss = 0.0f;
+            if (live) {
+                const char *src = f + (im * HW + pin) * C * 4 + in_off;
+                const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { v[j] = (float)hi[j] + (float)lo[j]; ss = fmaf(v[j], v[j], ss); m[j] = fmaxf(m[j], v[j]); }
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (!live) continue;
+            const float inv = kVScale / (sqrtf(ss) + 1e-10f * kVggAct);        // (A f) / (|A f| + A eps) = f / (|f| + eps)
+            char *row = V + im * ldv_bytes;
+            const int64_t k = off + pin * C + cb * 8;
+            h8 oh, ol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = v[j] * inv * cf[j];
+                oh[j] = (_Float16)t;
+                ol[j] = (_Float16)(t - (float)oh[j]);
+            }
+            if constexpr (H1) {
+                *reinterpret_cast<h8 *>(row + k * 2) = oh;
+            } else {
+                char *dst = row + split_off(k);
+                *reinterpret_cast<h8 *>(dst) = oh;
+                *reinterpret_cast<h8 *>(dst + 64) = ol;
+            }
+        }
+        if (!live) continue;
+        h8 ph, plo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)m[j]; plo[j] = (_Float16)(m[j] - (float)ph[j]); }
+        char *dst = pooled + (win * C) * 4 + in_off;
+        *reinterpret_cast<h8 *>(dst) = ph;
+        *reinterpret_cast<h8 *>(dst + 64) = plo;
+    }
+}
+
 int stream_blocks(int64_t items);
 
 template <bool H1>
@@ -436,6 +508,18 @@ void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, c
     case 128: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
     case 256: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
     default: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
+    }
+}
+
+template <bool H1>
+void launch_tap_pool_split(hipStream_t st, const char *f, int64_t n, int H, int W, int C, const float *coef, char *V, int64_t ldv, int64_t off, char *pooled)
+{
+    const dim3 grid((unsigned)stream_blocks(n * (H / 2) * (W / 2) * (C / 8)));
+    switch (C) {
+    case 64: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
+    case 128: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
+    case 256: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
+    default: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
     }
 }
 
@@ -1029,6 +1113,23 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             if (rc != GL_OK) return rc;
             cur = bufs[which];
             which ^= 1;
+            if (kAfter[ci] == 2 && h3) {
+                // tap + 2x2 max-pool in one pass over the activation
+                const int C = kCout[ci];
+                if (fmt)
+                    launch_tap_pool_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vc, ldv, off,
+                                                reinterpret_cast<char *>(bufs[which]));
+                else
+                    launch_tap_pool_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vc, ldv, off,
+                                                 reinterpret_cast<char *>(bufs[which]));
+                GL_LAUNCH_CHECK();
+                off += (int64_t)C * h * w;
+                coef_off += C;
+                cur = bufs[which];
+                which ^= 1;
+                h /= 2; w /= 2;
+                continue;
+            }
             if (kAfter[ci] >= 1) {
                 const int C = kCout[ci];
                 const dim3 tg((unsigned)stream_blocks(m * h * w * 64));

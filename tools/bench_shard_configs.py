@@ -68,15 +68,16 @@ def main():
         conv_ms, conv_n = prof["gather_conv"]
         ok = bool(np.array_equal(i[:len(planted)], np.minimum(planted, n_eff - 1))) if planted.max() < n_eff else None
         row_bytes = 2 * K1
-        slices = int(np.ceil(Q * row_bytes / (64 * 2 ** 30)))
+        from ganleaks_amd.attack import _budget_bytes, _query_budget_bytes
+        slices = int(np.ceil(Q * row_bytes / _query_budget_bytes(_budget_bytes())))
         emit(config="configs[3] one rank of 8: PGGAN-256, %d queries x %d-sample shard, 0.2*LPIPS+L2 at 256x256, streamed" % (Q, N),
              seconds=round(dt, 2), query_images_per_s_this_rank=round(Q / dt, 2), planted_found=ok,
              feat_knn={"launches": int(knn_n), "total_s": round(knn_ms / 1e3, 2), "alg_tflops": round(2.0 * Q * n_eff * K_alg / (knn_ms * 1e-3) / 1e12, 1),
                        "frac_of_fp16_peak": round(2.0 * Q * n_eff * K_alg / (knn_ms * 1e-3) / 2.5e15, 4), "K_search_row": K1},
              convolutions={"launches": int(conv_n), "total_s": round(conv_ms / 1e3, 2),
                            "note": "PGGAN-256 generator (56.3 GFLOP / image) + VGG16 at 256x256 (40.1 GFLOP / image) for the shard, once per query slice"},
-             query_slices=slices, note="a search row is %.1f MB: the queries go in %d slices of the 64 GiB budget and the bank shard is regenerated "
-             "and re-featurised once per slice" % (row_bytes / 1e6, slices))
+             query_slices=slices, note="a search row is %.1f MB; the %d query rows (%.0f GiB) %s; the bank shard is generated and featurised once per "
+             "query slice, in chunks" % (row_bytes / 1e6, Q, Q * row_bytes / 2 ** 30, "stay resident" if slices == 1 else "go in %d slices" % slices))
         del gen, model, queries
 
     if args.config in ("4", "all"):
