@@ -63,6 +63,9 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p, int phases);
 // output channels one workgroup tile of gl_launch_gather_conv_h3 will cover for this problem (the fused PixelNorm needs cols <= that)
 int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases);
+// halo form for narrow 3 x 3 layers at high resolution (gl_conv_halo.hip); same results bit for bit as gl_launch_gather_conv_h3's own kernel
+bool gl_conv_halo_applies(const GlGatherConv &p, int phases);
+int gl_launch_conv_halo_h3(gl_ctx *ctx, const GlGatherConv &p);
 // fp32 rows [n][d] -> split layout [n][dpad/32][128 B] of (value * scale)
 int gl_launch_split_rows(gl_ctx *ctx, const float *in, int64_t n, int d, int dpad, float scale, void *out);
 // host: packed fp32 weight rows [rows][K] -> split layout of (value * scale); `out` holds rows * K * 4 bytes
