@@ -34,11 +34,14 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 //   <2,4,8,4>: 256 channels x 256 positions, 8 waves of 128 x 64, 128 KiB LDS (1 workgroup per CU): wide layers of large passes
 //   <1,8,8,4>: 128 channels x 512 positions, 8 waves of 128 x 64, 160 KiB LDS: 65..128-column layers of large passes (PGGAN at 128 x 128,
 //              VGG16 conv2_x): +4.5 % on PGGAN-256 over <2,2,4,4> (A/B alternating on one device)
-// K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): a 128 x 256
+// K slices are double buffered with one __syncthreads() per slice.  Tried and dropped (no gain): the software pipeline
+// of gl_pair256.h on this kernel (inline-asm fragment reads with counted waits, a ring of two weight tiles, the barrier before the last
+// weight tile, DMA pieces spread over the weight tiles: bit-identical, 2-3 % SLOWER on every generator -- round 2), a 128 x 256
 // tile with 8 waves of 64 x 64, 256 x 256 with 4 waves of 128 x 128 (1 wave per SIMD), 128 x 512 / 128 x 256 tiles for 128-column
 // layers, a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU, staggered staging of the two wave halves,
 // halo staging (one staged pixel range per channel chunk, taps as shifted rows).
-template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false>
+// UP: the input is read through nearest-neighbour x2 upsampling (p.up; a template parameter so that the common form does not carry its registers)
+template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
 #if __HIP_DEVICE_COMPILE__
@@ -56,8 +59,8 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
     const int64_t m0 = (int64_t)mt * HTP;     // first position of the tile
     const int c0 = nt * HTC;                  // first output channel of the tile
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int wc = wave / WP, wp_ = wave % WP;         // wave position: channel block, position block
 
     const int K = p.ntaps * p.Cin;                     // in elements; a slice is 32 elements = 128 bytes
@@ -66,8 +69,8 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
     const uint32_t tdy = p.tap_dy[phase], tdx = p.tap_dx[phase];
     const char *wbase = reinterpret_cast<const char *>(p.wpack) + (int64_t)phase * p.cols_pad * K * 4;
 
-    const int rsub = lane >> 3, slot = lane & 7;
-    const int up = p.up;
+    const int rsub = lane0 >> 3, slot = lane0 & 7;
+    constexpr int up = UP ? 1 : 0;
     const int Ws = p.W >> up, Hs = p.H >> up;
     constexpr unsigned kOOB = 0xC0000000u;
     const unsigned lead_bytes = (unsigned)(p.W + 1) * (unsigned)p.Cin * 4u;
@@ -75,33 +78,33 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.in)) - (up ? 0 : (int64_t)lead_bytes), 0,
                                           (int)(p.in_bytes + (up ? 0u : 2u * lead_bytes)), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wbase), 0, (int)((unsigned)p.cols_pad * (unsigned)K * 4u), 0x00020000);
-    unsigned x_voff[PX], x_mask[PX], w_voff[PW];
-    int x_img[PX], x_y[PX], x_x[PX];
+    // per-lane offsets of piece 0; piece i of a wave lies 8 rows further: a wave-uniform distance that goes into the scalar offset
+    unsigned x_voff0 = kOOB, x_mask2[(PX + 1) / 2], w_voff0 = 0;      // tap masks of two pieces per word (ntaps <= 16)
 #pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        const int r = (wave * PW + i) * 8 + rsub;
-        w_voff[i] = ((unsigned)(c0 + r) * (unsigned)K) * 4u + (unsigned)(slot ^ (r & 7)) * 16u;
+    for (int i = 0; i < (PX + 1) / 2; ++i) x_mask2[i] = 0;
+    auto x_mask_of = [&](int i) -> unsigned { return (x_mask2[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu; };
+    int x_img[UP ? PX : 1], x_yx[UP ? PX : 1];            // UP only: first pixel of the image (low resolution), y | x << 16
+    {
+        const int r = wave * PW * 8 + rsub;                 // (r & 7) == rsub for every piece
+        w_voff0 = ((unsigned)(c0 + r) * (unsigned)K) * 4u + (unsigned)(slot ^ rsub) * 16u;
     }
+    const unsigned w_step = 8u * (unsigned)K * 4u, x_step = 8u * (unsigned)p.Cin * 4u;
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         const int r = (wave * PX + i) * 8 + rsub;
         const int chunk = slot ^ (r & 7);
         const int64_t pos = m0 + r;
-        x_mask[i] = 0;
-        x_voff[i] = kOOB;
-        x_img[i] = x_y[i] = x_x[i] = 0;
+        if constexpr (UP) { x_img[i] = 0; x_yx[i] = 0; }
         if (pos < p.positions) {
             const int64_t img = pos / HW;
             const int rem = (int)(pos - img * HW);
             const int y = rem / p.W, x = rem - y * p.W;
             for (int t = 0; t < p.ntaps; ++t) {
                 const int yy = y + (int)((tdy >> (2 * t)) & 3u) - 1, xx = x + (int)((tdx >> (2 * t)) & 3u) - 1;
-                if ((yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W)) x_mask[i] |= 1u << t;
+                if ((yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W)) x_mask2[i >> 1] |= 1u << (t + (i & 1) * 16);
             }
-            x_voff[i] = (unsigned)pos * (unsigned)p.Cin * 4u + (unsigned)chunk * 16u;
-            x_img[i] = (int)(img * Hs * Ws);
-            x_y[i] = y;
-            x_x[i] = x;
+            if (i == 0) x_voff0 = (unsigned)pos * (unsigned)p.Cin * 4u + (unsigned)chunk * 16u;      // pieces are 8 positions apart
+            if constexpr (UP) { x_img[i] = (int)(img * Hs * Ws); x_yx[i] = y | (x << 16); }
         }
     }
 
@@ -113,22 +116,22 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         const unsigned tapbit = 1u << tap;
 #pragma unroll
         for (int i = 0; i < PW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (gl_lptr)(buf + (wave * PW + i) * 1024), 16, w_voff[i], (unsigned)kt * 128u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (gl_lptr)(buf + (wave * PW + i) * 1024), 16, w_voff0, (unsigned)kt * 128u + (unsigned)i * w_step, 0, 0);
         if (!up) {
             const unsigned soff = (unsigned)(((dy + 1) * p.W + (dx + 1)) * p.Cin) * 4u + (unsigned)cc * 128u;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                const unsigned voff = (x_mask[i] & tapbit) ? x_voff[i] : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff, 0, 0);
+                const unsigned voff = (x_mask_of(i) & tapbit) ? x_voff0 : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff + (unsigned)i * x_step, 0, 0);
             }
         } else {
             const unsigned soff = (unsigned)cc * 128u;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 const int r = (wave * PX + i) * 8 + rsub;
-                const int yy = x_y[i] + dy, xx = x_x[i] + dx;
-                const unsigned pix = (unsigned)(x_img[i] + (yy >> 1) * Ws + (xx >> 1));
-                const unsigned voff = (x_mask[i] & tapbit) ? pix * (unsigned)p.Cin * 4u + (unsigned)((slot ^ (r & 7)) * 16) : kOOB;
+                const int yy = (x_yx[UP ? i : 0] & 0xFFFF) + dy, xx = (x_yx[UP ? i : 0] >> 16) + dx;
+                const unsigned pix = (unsigned)(x_img[UP ? i : 0] + (yy >> 1) * Ws + (xx >> 1));
+                const unsigned voff = (x_mask_of(i) & tapbit) ? pix * (unsigned)p.Cin * 4u + (unsigned)((slot ^ (r & 7)) * 16) : kOOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff, 0, 0);
             }
         }
@@ -140,22 +143,22 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    const int frow = lane & 15, fk = lane >> 4;
+    const int frow0 = lane0 & 15, fk0 = lane0 >> 4;
     auto compute = [&](const char *cur) {
         const char *lw = cur + (wc * 16 * TC) * HBK_BYTES;
         const char *lx = cur + W_BYTES + (wp_ * 16 * TP) * HBK_BYTES;
         v8h w_hi[TC], w_lo[TC], x_hi[TP], x_lo[TP];
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
-            const int r = i * 16 + frow;
-            w_hi[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
-            w_lo[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
+            const int r = i * 16 + frow0;
+            w_hi[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + ((fk0 ^ (r & 7)) << 4));
+            w_lo[i] = *reinterpret_cast<const v8h *>(lw + r * HBK_BYTES + (((4 + fk0) ^ (r & 7)) << 4));
         }
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
-            const int r = j * 16 + frow;
-            x_hi[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + ((fk ^ (r & 7)) << 4));
-            x_lo[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + (((4 + fk) ^ (r & 7)) << 4));
+            const int r = j * 16 + frow0;
+            x_hi[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + ((fk0 ^ (r & 7)) << 4));
+            x_lo[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + (((4 + fk0) ^ (r & 7)) << 4));
         }
 #pragma unroll
         for (int i = 0; i < TC; ++i)
@@ -175,6 +178,12 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
 
     // ---- epilogue.  C tile (16 x 16): column (position) = lane & 15, row (channel) = 4 * (lane >> 4) + reg.
     __syncthreads();
+    // the lane-derived indices are derived AGAIN here, behind an opaque copy of threadIdx.x, so that the ones above are dead during the main
+    // loop: the loop needs every register it can get (one spilled accumulator tile costs a scratch reload per slice -- and the
+    // s_waitcnt vmcnt(0) that comes with it drains the LDS-DMA queue)
+    int tid_again = threadIdx.x;
+    asm volatile("" : "+v"(tid_again));
+    const int tid = tid_again, lane = tid_again & 63, frow = tid_again & 15, fk = (tid_again & 63) >> 4;
     int *orow = reinterpret_cast<int *>(smem);
     if (tid < HTP) {
         const int64_t pos = m0 + tid;
@@ -287,15 +296,18 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 
 }  // namespace
 
-template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false>
+template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false>
 static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
+    if constexpr (!UP && !FUSE_TAIL) {
+        if (p.up) return launch_h3<WC, WP, TC, TP, FUSE_TAIL, true>(ctx, p, phases);
+    }
     constexpr int HTC = 16 * TC * WC, HTP = 16 * TP * WP;
     const int64_t m_tiles = gl_ceil_div(p.positions, HTP);
     const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
     constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
-    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP, FUSE_TAIL>;
+    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP, FUSE_TAIL, UP>;
     GL_ONCE_PER_DEVICE(ctx, \
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
@@ -354,7 +366,7 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE(p.pixnorm_act == 0.0f || (p.out_mode == 2 && !p.tail_w && phases == 1 && p.cols <= gl_conv_h3_tile_channels(p, phases)),
                "gather_conv_h3: the fused PixelNorm needs split output and all %d channels in one tile", p.cols);
     if (p.tail_w)
-        GL_REQUIRE((p.cols == 128 || p.cols == 64) && p.cmod == p.cols && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 64- or 128-channel layer");
+        GL_REQUIRE(p.up == 0 && (p.cols == 128 || p.cols == 64) && p.cmod == p.cols && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 64- or 128-channel layer");
     if (gl_conv_halo_applies(p, phases)) return gl_launch_conv_halo_h3(ctx, p);
     switch (h3_tile_choice(p, phases)) {
     case 3: return launch_h3<2, 2, 4, 4, true>(ctx, p, phases);
