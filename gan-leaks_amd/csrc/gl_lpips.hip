@@ -36,41 +36,6 @@ __constant__ float c_scale[3] = {.458f, .448f, .450f};      // networks_basic.py
 __device__ __forceinline__ float load_pixel(const uint8_t *p, const float *lut) { return lut[*p]; }
 __device__ __forceinline__ float load_pixel(const float *p, const float *) { return *p; }
 
-// image [n][3][H][W] (u8 codes or fp32 in [-1,1]) -> scaled, 3x3-im2col'ed NHWC [n][H][W][32]:
-// channel (ky*3+kx)*3 + c = ((x - shift_c) / scale_c) at (y+ky-1, x+kx-1), 0 outside the image (the conv's zero
-// padding acts on the scaled tensor), channels 27..31 = 0.
-template <typename T>
-__global__ void __launch_bounds__(256) vgg_input_kernel(const T *__restrict__ img, int64_t n, int H, int W, float *__restrict__ out)
-{
-    __shared__ float lut[256];
-    lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);   // attack_models/utils.py:82
-    __syncthreads();
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n * H * W) return;
-    const int64_t im = gid / (H * W);
-    const int rem = (int)(gid - im * (H * W));
-    const int y = rem / W, x = rem - y * W;
-    float v[32];
-#pragma unroll
-    for (int k = 27; k < 32; ++k) v[k] = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float t = 0.0f;
-                if (ok) t = __fdiv_rn(__fsub_rn(load_pixel(img + ((im * 3 + c) * H + yy) * (int64_t)W + xx, lut), c_shift[c]), c_scale[c]);
-                v[(ky * 3 + kx) * 3 + c] = t;
-            }
-        }
-    float4 *o = reinterpret_cast<float4 *>(out + gid * 32);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-}
-
 // 2x2 / stride 2 max-pool, NHWC, C % 4 == 0
 __global__ void __launch_bounds__(256) maxpool2_nhwc_kernel(const float *__restrict__ in, int64_t n, int H, int W, int C, float *__restrict__ out)
 {
@@ -300,40 +265,127 @@ __global__ void __launch_bounds__(256) feat_rows_dist_kernel(const char *__restr
 // ---------------------------------------------------------------------------------------------
 constexpr float kVggAct = 4.0f;
 
-// image -> scaled, 3x3-im2col'ed, split layout: one 128-byte chunk (27 values + 5 zeros, hi | lo) per position
-template <typename T>
-__global__ void __launch_bounds__(256) vgg_input_split_kernel(const T *__restrict__ img, int64_t n, int H, int W, char *__restrict__ out)
+// conv1_1 (3 -> 64 channels, 3x3, pad 1) + ReLU straight from the image, on the fp32-input matrix instruction (v_mfma_f32_32x32x2_f32: exact
+// fp32, an fmaf chain over k): the scaled input tensor is never materialised.  A = weights [64 channels][k], k = (ky*3+kx)*3 + c (28 of
+// the packed 32 columns), held in registers; B = the 27 scaled taps of 32 consecutive positions, gathered from the image; C: lane = position,
+// registers = channels, turned through LDS so that every lane stores 16 contiguous bytes.  One wave owns 32 positions per iteration.
+// SPLIT: activations * kVggAct in the split layout, else fp32 NHWC (256 bytes per position either way).
+__device__ __forceinline__ float conv1_tap(uint8_t code, int c, const float (*lut)[256], float) { return lut[c][code]; }
+__device__ __forceinline__ float conv1_tap(float v, int c, const float (*)[256], float act) { return __fdiv_rn(__fsub_rn(v, c_shift[c]), c_scale[c]) * act; }
+
+template <typename T, bool SPLIT>
+__global__ void __launch_bounds__(256, 3) vgg_conv1_kernel(const T *__restrict__ img, int n, int H, int W, const float *__restrict__ wpack,
+                                                           const float *__restrict__ bias, char *__restrict__ out, int *__restrict__ sat_flag)
 {
-    __shared__ float lut[256];
-    lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
+    typedef float v16f __attribute__((ext_vector_type(16)));
+    typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+    constexpr int kRow = 272;                                   // bytes of LDS per position (256 + padding)
+    __shared__ float lut[3][256];                               // code -> ((2 code / 255 - 1) - shift_c) / scale_c * act (attack_models/utils.py:82)
+    __shared__ __attribute__((aligned(16))) char turn[4][32 * kRow];
+    const float act = SPLIT ? kVggAct : 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        lut[c][threadIdx.x] = __fdiv_rn(__fsub_rn((float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0), c_shift[c]), c_scale[c]) * act;
     __syncthreads();
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n * H * W) return;
-    const int64_t im = gid / (H * W);
-    const int rem = (int)(gid - im * (H * W));
-    const int y = rem / W, x = rem - y * W;
-    _Float16 hi[32], lo[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    float wa[2][14];
 #pragma unroll
-    for (int k = 27; k < 32; ++k) { hi[k] = (_Float16)0.0f; lo[k] = (_Float16)0.0f; }
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+        for (int s = 0; s < 14; ++s) wa[t][s] = wpack[(t * 32 + col) * 32 + 2 * s + half];
+    // k = 27 (the first of the packed row's zero columns) carries the bias: its "tap" is the constant act
+    if (half) { wa[0][13] = bias[col]; wa[1][13] = bias[32 + col]; }
+    const int HW = H * W;
+    const int total = n * HW;                                   // positions of the pass (host-checked: n * 3 * H * W < 2^31)
+    const int groups = (total + 31) / 32;
+    const int stride = (int)gridDim.x * 4;
+    char *mine = turn[wave];
+    bool saturated = false;
+
+    // the 14 taps of this lane (k = 2 s + half) for position group g: unconditional loads from clamped offsets, all in flight together;
+    // bit s of okm: the tap lies inside the image
+    auto fetch = [&](int g, T (&raw)[14], uint32_t &okm) {
+        const int pos = g * 32 + col;
+        const bool live = (g < groups) & (pos < total);
+        const int im = live ? pos / HW : 0;
+        const int rem = live ? pos - im * HW : 0;
+        const int y = rem / W, x = rem - y * W;
+        const int at = im * 3 * HW + rem;
+        okm = 0;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            const bool ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float t = 0.0f;
-                if (ok) t = __fdiv_rn(__fsub_rn(load_pixel(img + ((im * 3 + c) * H + yy) * (int64_t)W + xx, lut), c_shift[c]), c_scale[c]) * kVggAct;
-                const _Float16 h = (_Float16)t;
-                hi[(ky * 3 + kx) * 3 + c] = h;
-                lo[(ky * 3 + kx) * 3 + c] = (_Float16)(t - (float)h);
-            }
+        for (int s = 0; s < 14; ++s) {
+            const int k0 = 2 * s, k1 = 2 * s + 1;
+            const int c0 = k0 % 3, ky0 = (k0 / 3) / 3, kx0 = (k0 / 3) % 3;
+            const int c1 = k1 % 3, ky1 = (k1 / 3) / 3, kx1 = (k1 / 3) % 3;
+            const int c = half ? c1 : c0, dy = (half ? ky1 : ky0) - 1, dx = (half ? kx1 : kx0) - 1;
+            const bool real = half ? (k1 < 27) : (k0 < 27);
+            const int yy = y + dy, xx = x + dx;
+            const bool ok = live & real & (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W);
+            okm |= ok ? 1u << s : 0u;
+            raw[s] = img[ok ? at + c * HW + dy * W + dx : 0];
         }
-    uint4 *o = reinterpret_cast<uint4 *>(out + gid * 128);
-    const uint4 *ph = reinterpret_cast<const uint4 *>(hi), *pl = reinterpret_cast<const uint4 *>(lo);
+        if (live & (half != 0)) okm |= 1u << 14;                // the bias tap
+    };
+
+    T raw[14];
+    uint32_t okm;
+    int g = (int)blockIdx.x * 4 + wave;
+    fetch(g, raw, okm);
+    for (; g < groups; g += stride) {
+        float b[14];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { o[k] = ph[k]; o[4 + k] = pl[k]; }
+        for (int s = 0; s < 14; ++s) {
+            const int c = half ? (2 * s + 1) % 3 : (2 * s) % 3;
+            b[s] = conv1_tap(raw[s], c, lut, act) * ((okm >> s) & 1u ? 1.0f : 0.0f);
+        }
+        if ((okm >> 14) & 1u) b[13] = act;
+        fetch(g + stride, raw, okm);                            // the next group's taps travel while this one multiplies
+        v16f acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][s], b[s], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[1][s], b[s], acc[1], 0, 0, 0);
+        }
+        // C: column (position) = lane & 31, row (channel within the tile) = (r & 3) + 8 (r >> 2) + 4 half
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = t * 32 + 8 * q + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[t][4 * q + r], 0.0f);
+                if constexpr (SPLIT) {
+                    char *dst = mine + col * kRow + t * 128 + (ch & 31) * 2;
+                    v4h hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float cl = fminf(v[r], 65504.0f);
+                        saturated |= cl != v[r];
+                        hi[r] = (_Float16)cl;
+                        lo[r] = (_Float16)__fsub_rn(cl, (float)hi[r]);
+                    }
+                    *reinterpret_cast<v4h *>(dst) = hi;
+                    *reinterpret_cast<v4h *>(dst + 64) = lo;
+                } else {
+                    *reinterpret_cast<float4 *>(mine + col * kRow + ch * 4) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int pp = it * 4 + (lane >> 4), chunk = lane & 15;
+            const uint4 v = *reinterpret_cast<const uint4 *>(mine + pp * kRow + chunk * 16);
+            if (g * 32 + pp < total) *reinterpret_cast<uint4 *>(out + (int64_t)(g * 32 + pp) * 256 + chunk * 16) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (SPLIT && __any(saturated) && lane == 0) atomicAdd(sat_flag, 1);
 }
 
 // 2x2 / stride 2 max-pool on the split layout; one thread per 8 channels of an output position (C % 32 == 0)
@@ -999,7 +1051,7 @@ struct gl_lpips {
     // workspace for `chunk` images of H x W
     int64_t chunk, ws_imgs;
     int ws_H, ws_W;
-    float *ws_in, *ws_a, *ws_b, *ws_coef;
+    float *ws_a, *ws_b, *ws_coef;
 };
 
 namespace {
@@ -1022,11 +1074,10 @@ int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
     if (n < want) want = n;
     if (want <= l->ws_imgs && H == l->ws_H && W == l->ws_W) return GL_OK;
     GL_HIP(hipStreamSynchronize(l->ctx->stream));
-    (void)hipFree(l->ws_in); (void)hipFree(l->ws_a); (void)hipFree(l->ws_b);
-    l->ws_in = l->ws_a = l->ws_b = nullptr;
+    (void)hipFree(l->ws_a); (void)hipFree(l->ws_b);
+    l->ws_a = l->ws_b = nullptr;
     l->ws_imgs = 0;
     const size_t px = (size_t)want * H * W;
-    GL_HIP(hipMalloc((void **)&l->ws_in, px * 32 * 4));
     GL_HIP(hipMalloc((void **)&l->ws_a, px * 64 * 4));      // largest activation: H x W x 64
     GL_HIP(hipMalloc((void **)&l->ws_b, px * 64 * 4));
     l->ws_imgs = want; l->ws_H = H; l->ws_W = W;
@@ -1080,22 +1131,29 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
         const int64_t m = (n - i0 < l->ws_imgs) ? n - i0 : l->ws_imgs;
         char *Vc = reinterpret_cast<char *>(V_dev) + i0 * ldv;
         const bool h3 = l->precision == 1;
-        if (h3)
-            hipLaunchKernelGGL(vgg_input_split_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W,
-                               reinterpret_cast<char *>(l->ws_in));
-        else
-            hipLaunchKernelGGL(vgg_input_kernel<T>, dim3((unsigned)gl_ceil_div(m * H * W, 256)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, H, W, l->ws_in);
-        GL_LAUNCH_CHECK();
-        const float *cur = l->ws_in;
+        const float *cur = nullptr;
         float *bufs[2] = {l->ws_a, l->ws_b};
         int which = 0, h = H, w = W;
         int64_t off = 0, coef_off = 0;
         for (int ci = 0; ci < kNumConv; ++ci) {
+            if (ci == 0) {
+                // conv1_1 reads the image itself
+                const unsigned nb = (unsigned)std::min<int64_t>(gl_ceil_div(m * h * w, 128), (int64_t)ctx->num_cu * 8);
+                if (h3)
+                    hipLaunchKernelGGL((vgg_conv1_kernel<T, true>), dim3(nb), dim3(256), 0, ctx->stream, img_dev + i0 * D, (int)m, h, w, l->w[0], l->bias[0],
+                                       reinterpret_cast<char *>(bufs[which]), ctx->h3_sat);
+                else
+                    hipLaunchKernelGGL((vgg_conv1_kernel<T, false>), dim3(nb), dim3(256), 0, ctx->stream, img_dev + i0 * D, (int)m, h, w, l->w[0], l->bias[0],
+                                       reinterpret_cast<char *>(bufs[which]), ctx->h3_sat);
+                GL_LAUNCH_CHECK();
+                cur = bufs[which];
+                which ^= 1;
+                continue;
+            }
             GlGatherConv p = {};
             p.in = cur; p.positions = m * h * w; p.H = h; p.W = w;
             p.wpack = l->w[ci]; p.cols = kCout[ci]; p.cols_pad = kCout[ci];
-            if (ci == 0) { p.Cin = 32; p.ntaps = 1; p.tap_dy[0] = 1; p.tap_dx[0] = 1; }
-            else {
+            {
                 p.Cin = kCin[ci]; p.ntaps = 9;
                 uint32_t dy = 0, dx = 0;
                 for (int t = 0; t < 9; ++t) { dy |= (uint32_t)(t / 3) << (2 * t); dx |= (uint32_t)(t % 3) << (2 * t); }
@@ -1190,7 +1248,7 @@ int gl_lpips_create(gl_ctx *ctx, gl_lpips **out)
     for (int i = 0; i < 5; ++i) { l->lin[i] = nullptr; l->have_lin[i] = false; }
     l->ones = nullptr;
     l->chunk = 0; l->ws_imgs = 0; l->ws_H = l->ws_W = 0;
-    l->ws_in = l->ws_a = l->ws_b = l->ws_coef = nullptr;
+    l->ws_a = l->ws_b = l->ws_coef = nullptr;
     std::vector<float> one(512, 1.0f);
     int rc = lp_upload(ctx, &l->ones, one);
     if (rc != GL_OK) { delete l; return rc; }
@@ -1205,7 +1263,7 @@ int gl_lpips_destroy(gl_lpips *l)
     (void)hipStreamSynchronize(l->ctx->stream);
     for (int i = 0; i < kNumConv; ++i) { (void)hipFree(l->w[i]); (void)hipFree(l->bias[i]); (void)hipFree(l->wsplit[i]); (void)hipFree(l->scale_h3[i]); (void)hipFree(l->bias_h3[i]); }
     for (int i = 0; i < 5; ++i) (void)hipFree(l->lin[i]);
-    (void)hipFree(l->ones); (void)hipFree(l->ws_in); (void)hipFree(l->ws_a); (void)hipFree(l->ws_b); (void)hipFree(l->ws_coef);
+    (void)hipFree(l->ones); (void)hipFree(l->ws_a); (void)hipFree(l->ws_b); (void)hipFree(l->ws_coef);
     delete l;
     return GL_OK;
 }
@@ -1234,7 +1292,7 @@ int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *
     auto Wt = [&](int co, int ci, int ky, int kx) { return w[(((int64_t)co * ci_n + ci) * 3 + ky) * 3 + kx]; };
     std::vector<float> pk;
     if (conv_index == 0) {
-        pk.assign((size_t)co_n * 32, 0.0f);     // K = 32: (ky*3+kx)*3 + c, matching vgg_input_kernel
+        pk.assign((size_t)co_n * 32, 0.0f);     // K = 32: (ky*3+kx)*3 + c, as vgg_conv1_kernel walks it
         for (int co = 0; co < co_n; ++co)
             for (int ky = 0; ky < 3; ++ky)
                 for (int kx = 0; kx < 3; ++kx)
