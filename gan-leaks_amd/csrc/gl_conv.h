@@ -47,7 +47,32 @@ struct GlGatherConv {
     // PGGAN's PixelNorm (gan_models/pggan/model_torch.py:25-31) applied to the activated outputs before they are stored,
     // v -> v / sqrt(mean_c v^2 / A^2 + 1e-8) with A = pixnorm_act the factor the stored activations carry; 0 = off
     float pixnorm_act;
+    // gather_conv_h3 only, optional (same condition on the tile, see gl_conv_h3_tap_fusable): an LPIPS tap (attack_models/lpips.py:110-118,
+    // normalize_tensor + the lin layer's weights) and the 2 x 2 max-pool that follows it, taken from the activated outputs in the epilogue:
+    //   V[img][tap_off + pin * cols + c] = v / (|v|_channels + eps) * tap_coef[c]   (pin = position inside the image; tap_fmt 1: fp16 row
+    //   of tap_ldv bytes, 0: split row), tap_pool[img][y/2][x/2][c] = max of the 2 x 2 window in the split layout.  `out` is NOT written.
+    // The sum of squares over the channels uses the epilogue's canonical order (gl_conv_h3_epi.h), which lpips_tap_*_split_kernel repeat.
+    char *tap_V;                // nullptr = off
+    const float *tap_coef;
+    int64_t tap_ldv, tap_off;
+    int tap_fmt;
+    char *tap_pool;
+    float tap_scale, tap_eps;   // V = v * (tap_scale / (sqrt(sum v^2) + tap_eps)) * coef
 };
+
+#if defined(__HIPCC__)
+// (v * inv) * coef with both products rounded to fp32 and MATERIALISED: without the empty asm hipcc is free to fold a product into the
+// conversion or subtraction that follows it (v_fma_mix*, fma contraction), differently in different kernels, and the fused and the
+// stand-alone tap would stop agreeing bit for bit.
+__device__ __forceinline__ float gl_tap_value(float v, float inv, float coef)
+{
+    float x = v * inv;
+    asm volatile("" : "+v"(x));
+    float t = x * coef;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+#endif
 
 // host: rows [48][channels] (channels = 64 or 128) of fp32 tail weights (row = GEMM column) -> the operand image the fused epilogue reads
 // (12 KiB per 64 channels): [channel half][column tile 3][k step 2][hi | lo][row 16][k group 4][8 halves], the 8 halves of k group g holding
@@ -63,6 +88,8 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p, int phases);
 // output channels one workgroup tile of gl_launch_gather_conv_h3 will cover for this problem (the fused PixelNorm needs cols <= that)
 int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases);
+// whether gl_launch_gather_conv_h3 can take the tap_* fields for this problem (all channels in one tile, the 2 x 2 window inside one wave)
+bool gl_conv_h3_tap_fusable(const GlGatherConv &p, int phases);
 // halo form for narrow 3 x 3 layers at high resolution (gl_conv_halo.hip); same results bit for bit as gl_launch_gather_conv_h3's own kernel
 bool gl_conv_halo_applies(const GlGatherConv &p, int phases);
 int gl_launch_conv_halo_h3(gl_ctx *ctx, const GlGatherConv &p);

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                 }
         }
     } else {
-        saturated |= gl_h3::epilogue<WC, WP, TC, TP>(p, acc, c0, wc, wp_, lane, o4, smem);
+        saturated |= gl_h3::epilogue<WC, WP, TC, TP>(p, acc, c0, wc, wp_, lane, o4, smem, p.tap_V ? (p.Wo >> 4) : 0);
     }
     if (__any(saturated) && lane == 0) atomicAdd(p.sat_flag, 1);
 #endif
@@ -341,6 +341,16 @@ int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases)
     return t == 2 ? 256 : (t == 1 || t == 4) ? 64 : 128;       // tiles 0, 3 and 5 hold 128 channels
 }
 
+bool gl_conv_h3_tap_fusable(const GlGatherConv &p, int phases)
+{
+    static const int enabled = getenv("GL_TAP_FUSE") ? atoi(getenv("GL_TAP_FUSE")) : 1;
+    if (!enabled || phases != 1 || p.tail_w || p.out_mode != 2 || p.omul != 1 || p.Ho != p.H || p.Wo != p.W || p.planar) return false;
+    if (p.cols > gl_conv_h3_tile_channels(p, phases) || p.H % 2 != 0 || p.W % 16 != 0) return false;
+    if (gl_conv_halo_applies(p, phases)) return true;           // a wave owns 4 rows of its 16 x 16 block
+    // tap-gather tiles: a wave owns 64 consecutive positions, which must hold whole pairs of rows
+    return (p.W == 16 || p.W == 32) && p.positions % 64 == 0;
+}
+
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
 {
     gl_make_current(ctx);
@@ -365,6 +375,7 @@ int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p_in, int phases)
     GL_REQUIRE(p.positions < (1ll << 31) && (p.positions / ((int64_t)p.H * p.W)) * p.Ho * p.Wo < (1ll << 31), "gather_conv_h3: too many positions");
     GL_REQUIRE(p.pixnorm_act == 0.0f || (p.out_mode == 2 && !p.tail_w && phases == 1 && p.cols <= gl_conv_h3_tile_channels(p, phases)),
                "gather_conv_h3: the fused PixelNorm needs split output and all %d channels in one tile", p.cols);
+    GL_REQUIRE(!p.tap_V || (p.pixnorm_act == 0.0f && p.tap_coef && gl_conv_h3_tap_fusable(p, phases)), "gather_conv_h3: this layer's tap cannot be fused");
     if (p.tail_w)
         GL_REQUIRE(p.up == 0 && (p.cols == 128 || p.cols == 64) && p.cmod == p.cols && p.tail_out && p.tail_ld > 0, "gather_conv_h3: the fused tail needs a 64- or 128-channel layer");
     if (gl_conv_halo_applies(p, phases)) return gl_launch_conv_halo_h3(ctx, p);

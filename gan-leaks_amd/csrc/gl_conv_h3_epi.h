@@ -4,6 +4,7 @@
 // WC x WP waves.  o4[j]: output position index of the lane's column in position tile j (-1: none).
 #pragma once
 #include "gl_conv.h"
+#include <type_traits>
 
 namespace gl_h3 {
 
@@ -11,9 +12,11 @@ typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// returns whether a split store of this lane had to clamp to the fp16 range
+// returns whether a split store of this lane had to clamp to the fp16 range.
+// pool_dj: position tile j ^ pool_dj holds the row below / above tile j's (fused tap + pool only; 0 when the caller never fuses one)
 template <int WC, int WP, int TC, int TP>
-__device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][TP], int c0, int wc, int wp_, int lane, const int (&o4)[TP], char *smem)
+__device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][TP], int c0, int wc, int wp_, int lane, const int (&o4)[TP], char *smem,
+                                         int pool_dj = 0)
 {
     const int frow = lane & 15, fk = lane >> 4;
     const float relu_floor = p.act == 1 ? 0.0f : -__builtin_inff();
@@ -25,10 +28,11 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
     // which pixelnorm_split_kernel (gl_pggan.hip) reproduces on stored values: fused or not, and whatever the tile shape, the stored
     // activations are bit-identical (a pass of another size may pick another tile).  Pass 2 below stores v * inv.
     const bool pixnorm = p.pixnorm_act > 0.0f;
+    const bool tap = p.tap_V != nullptr;
     float pinv[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) pinv[j] = 1.0f;
-    if (pixnorm) {
+    if (pixnorm || tap) {
         float tss[TC][TP];
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -93,6 +97,76 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
                     for (int k = 0; k < NT; k += 2 * w) t[k] = __fadd_rn(t[k], t[k + w]);
                 ss[j] = t[0];
             }
+        }
+        if (tap) {
+            // ---- LPIPS tap (+ 2 x 2 max-pool) from the rounded activations in acc; nothing else is stored
+#pragma unroll
+            for (int j = 0; j < TP; ++j) pinv[j] = __fdiv_rn(p.tap_scale, __fadd_rn(__fsqrt_rn(ss[j]), p.tap_eps));
+            const int HW = p.Ho * p.Wo, Wp = p.Wo >> 1;
+            int img[TP], pin[TP];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int o = o4[j] >= 0 ? o4[j] : 0;
+                img[j] = o / HW;
+                pin[j] = o - img[j] * HW;
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i) {
+                const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;
+                if (ch >= p.cols) continue;
+                float cf[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cf[r] = p.tap_coef[ch + r];
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    if (o4[j] < 0) continue;
+                    v4h oh, ol;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = gl_tap_value(acc[i][j][r], pinv[j], cf[r]);
+                        oh[r] = (_Float16)t;
+                        ol[r] = (_Float16)__fsub_rn(t, (float)oh[r]);
+                    }
+                    const int64_t k = p.tap_off + (int64_t)pin[j] * p.cols + ch;
+                    char *row = p.tap_V + (int64_t)img[j] * p.tap_ldv;
+                    if (p.tap_fmt) {
+                        *reinterpret_cast<v4h *>(row + k * 2) = oh;
+                    } else {
+                        char *dst = row + (k >> 5) * 128 + (k & 31) * 2;
+                        *reinterpret_cast<v4h *>(dst) = oh;
+                        *reinterpret_cast<v4h *>(dst + 64) = ol;
+                    }
+                }
+                if (p.tap_pool) {
+                    auto pool = [&](auto dj_c) {
+                        constexpr int DJ = decltype(dj_c)::value;
+#pragma unroll
+                        for (int j = 0; j < TP; ++j) {
+                            if ((j & DJ) != 0) continue;                  // the lower row of a pair of tiles is handled with the upper one
+                            float m[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                m[r] = fmaxf(acc[i][j][r], acc[i][(j ^ DJ) % TP][r]);
+                                m[r] = fmaxf(m[r], __shfl_xor(m[r], 1, 64));   // the column next to it
+                            }
+                            if ((frow & 1) != 0 || o4[j] < 0) continue;
+                            const int y = pin[j] / p.Wo, x = pin[j] - y * p.Wo;
+                            char *dst = p.tap_pool + ((int64_t)img[j] * (HW >> 2) + (y >> 1) * Wp + (x >> 1)) * p.cols * 4 + (ch >> 5) * 128 + (ch & 31) * 2;
+                            v4h hi, lo;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                hi[r] = (_Float16)m[r];
+                                lo[r] = (_Float16)__fsub_rn(m[r], (float)hi[r]);
+                            }
+                            *reinterpret_cast<v4h *>(dst) = hi;
+                            *reinterpret_cast<v4h *>(dst + 64) = lo;
+                        }
+                    };
+                    if (pool_dj == 1) pool(std::integral_constant<int, 1>());
+                    else pool(std::integral_constant<int, 2>());
+                }
+            }
+            return saturated;
         }
         const float A = p.pixnorm_act;
 #pragma unroll

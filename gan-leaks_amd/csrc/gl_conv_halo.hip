@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
     int o4[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) o4[j] = (img * p.Ho + y0 + wp_ * 4 + j) * p.Wo + x0 + frow;
-    const bool saturated = gl_h3::epilogue<WC, WP, TC, TP>(p, acc, 0, wc, wp_, lane, o4, smem);
+    const bool saturated = gl_h3::epilogue<WC, WP, TC, TP>(p, acc, 0, wc, wp_, lane, o4, smem, 1);
     if (__any(saturated) && lane == 0) atomicAdd(p.sat_flag, 1);
 #endif
 }

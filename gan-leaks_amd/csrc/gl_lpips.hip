@@ -423,6 +423,26 @@ __global__ void __launch_bounds__(256) maxpool2_split_kernel(const char *__restr
     }
 }
 
+// Sum of squares over the channels of a position in the convolution epilogue's canonical order (gl_conv_h3_epi.h), so that a tap taken
+// in the epilogue and one taken here from the stored activation give the same bits: per 16-channel tile, 4 groups of 4 consecutive
+// channels, each an fmaf chain from 0, combined as (g0 + g1) + (g2 + g3); then a balanced binary tree over the tiles.  A lane owns 8
+// channels = 2 groups; lanes 2 t and 2 t + 1 hold tile t.
+constexpr float kTapEps = 1e-10f * kVggAct;
+__device__ __forceinline__ float tap_sumsq8(const float (&v)[8])
+{
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a = fmaf(v[j], v[j], a); b = fmaf(v[4 + j], v[4 + j], b); }
+    return __fadd_rn(a, b);
+}
+template <int G>
+__device__ __forceinline__ float tap_sumsq_across(float s)
+{
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) s = __fadd_rn(s, __shfl_xor(s, o, 64));
+    return s;
+}
+
 // lpips_tap_kernel for split-layout activations (values carry the factor kVggAct, which cancels in the normalisation).
 // A lane owns 8 consecutive channels (16 B of hi halves + 16 B of lo halves); C / 8 lanes share a position, so a wave covers
 // 512 / C positions per pass with 2 KiB of contiguous reads and C * 2 (or 4) bytes of contiguous writes per position.
@@ -451,21 +471,21 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
             const char *src = f + pos * C * 4 + in_off;
             const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[j] = (float)hi[j] + (float)lo[j]; ss = fmaf(v[j], v[j], ss); }
+            for (int j = 0; j < 8; ++j) v[j] = __fadd_rn((float)hi[j], (float)lo[j]);
+            ss = tap_sumsq8(v);
         }
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        ss = tap_sumsq_across<G>(ss);
         if (!live) continue;
-        const float inv = kVScale / (sqrtf(ss) + 1e-10f * kVggAct);        // (A f) / (|A f| + A eps) = f / (|f| + eps)
+        const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), kTapEps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
         const int64_t im = pos / HW;
         char *row = V + im * ldv_bytes;
         const int64_t k = off + (pos - im * HW) * C + cb * 8;
         h8 oh, ol;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float t = v[j] * inv * cf[j];
+            const float t = gl_tap_value(v[j], inv, cf[j]);
             oh[j] = (_Float16)t;
-            ol[j] = (_Float16)(t - (float)oh[j]);
+            ol[j] = (_Float16)__fsub_rn(t, (float)oh[j]);
         }
         if constexpr (H1) {
             *reinterpret_cast<h8 *>(row + k * 2) = oh;
@@ -516,20 +536,20 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
                 const char *src = f + (im * HW + pin) * C * 4 + in_off;
                 const h8 hi = *reinterpret_cast<const h8 *>(src), lo = *reinterpret_cast<const h8 *>(src + 64);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { v[j] = (float)hi[j] + (float)lo[j]; ss = fmaf(v[j], v[j], ss); m[j] = fmaxf(m[j], v[j]); }
+                for (int j = 0; j < 8; ++j) { v[j] = __fadd_rn((float)hi[j], (float)lo[j]); m[j] = fmaxf(m[j], v[j]); }
+                ss = tap_sumsq8(v);
             }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            ss = tap_sumsq_across<G>(ss);
             if (!live) continue;
-            const float inv = kVScale / (sqrtf(ss) + 1e-10f * kVggAct);        // (A f) / (|A f| + A eps) = f / (|f| + eps)
+            const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), kTapEps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
             char *row = V + im * ldv_bytes;
             const int64_t k = off + pin * C + cb * 8;
             h8 oh, ol;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = v[j] * inv * cf[j];
+                const float t = gl_tap_value(v[j], inv, cf[j]);
                 oh[j] = (_Float16)t;
-                ol[j] = (_Float16)(t - (float)oh[j]);
+                ol[j] = (_Float16)__fsub_rn(t, (float)oh[j]);
             }
             if constexpr (H1) {
                 *reinterpret_cast<h8 *>(row + k * 2) = oh;
@@ -542,7 +562,7 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
         if (!live) continue;
         h8 ph, plo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)m[j]; plo[j] = (_Float16)(m[j] - (float)ph[j]); }
+        for (int j = 0; j < 8; ++j) { ph[j] = (_Float16)m[j]; plo[j] = (_Float16)__fsub_rn(m[j], (float)ph[j]); }
         char *dst = pooled + (win * C) * 4 + in_off;
         *reinterpret_cast<h8 *>(dst) = ph;
         *reinterpret_cast<h8 *>(dst + 64) = plo;
@@ -1164,6 +1184,20 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             if (h3) {
                 p.wpack = l->wsplit[ci]; p.cols_pad = (int)gl_ceil_div(kCout[ci], 128) * 128;
                 p.scale = l->scale_h3[ci]; p.shift = l->bias_h3[ci]; p.out_mode = 2;
+                if (kAfter[ci] == 2 && gl_conv_h3_tap_fusable(p, 1)) {
+                    // tap + 2x2 max-pool in the convolution's epilogue: the full-resolution activation is never stored
+                    const int C = kCout[ci];
+                    p.tap_V = Vc; p.tap_coef = l->ws_coef + coef_off; p.tap_ldv = ldv; p.tap_off = off; p.tap_fmt = fmt ? 1 : 0;
+                    p.tap_pool = reinterpret_cast<char *>(bufs[which]); p.tap_scale = kVScale; p.tap_eps = kTapEps;
+                    rc = gl_launch_gather_conv_h3(ctx, p, 1);
+                    if (rc != GL_OK) return rc;
+                    off += (int64_t)C * h * w;
+                    coef_off += C;
+                    cur = bufs[which];
+                    which ^= 1;
+                    h /= 2; w /= 2;
+                    continue;
+                }
                 rc = gl_launch_gather_conv_h3(ctx, p, 1);
             } else {
                 rc = gl_launch_gather_conv(ctx, p, 1);
