@@ -161,36 +161,49 @@ __global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict_
 }
 
 // |row|^2 of a search row (unscaled): sum over the LPIPS halves of h^2 + sum over the image part of (hi + lo)^2
-__global__ void __launch_bounds__(256) row_sqnorm_h1_kernel(const char *__restrict__ V, int64_t n, int64_t K_lp, int64_t Dp, int lo_seg, float *__restrict__ out)
+constexpr int kNormSeg = 32768;          // halves of a row per workgroup
+__global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__restrict__ V, int64_t K_lp, int64_t Dp, int lo_seg, int nseg,
+                                                                  double *__restrict__ part)
 {
+    // grid (segment, row): a 17 MB row of a 256 x 256 image is summed by 262 workgroups, not one (passes of that size have 128 rows); the
+    // segmentation depends on the row length only, so a row's norm does not depend on the pass it is computed in
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     __shared__ double red[256];
     const int64_t K1 = K_lp + 3 * Dp;
-    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const _Float16 *row = reinterpret_cast<const _Float16 *>(V + r * K1 * 2);
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        for (int64_t k = (int64_t)threadIdx.x * 8; k < K_lp + Dp; k += 256 * 8) {
-            const h8 h = *reinterpret_cast<const h8 *>(row + k);
-            float v[8];
+    const int64_t r = blockIdx.y;
+    const _Float16 *row = reinterpret_cast<const _Float16 *>(V + r * K1 * 2);
+    const int64_t k0 = (int64_t)blockIdx.x * kNormSeg;
+    const int64_t kend = k0 + kNormSeg < K_lp + Dp ? k0 + kNormSeg : K_lp + Dp;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int64_t k = k0 + (int64_t)threadIdx.x * 8; k < kend; k += 256 * 8) {
+        const h8 h = *reinterpret_cast<const h8 *>(row + k);
+        float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-            if (k >= K_lp) {
-                const h8 l = *reinterpret_cast<const h8 *>(row + k + lo_seg * Dp);
+        for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
+        if (k >= K_lp) {
+            const h8 l = *reinterpret_cast<const h8 *>(row + k + lo_seg * Dp);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
-            }
-            s0 = fmaf(v[0], v[0], s0); s1 = fmaf(v[1], v[1], s1); s2 = fmaf(v[2], v[2], s2); s3 = fmaf(v[3], v[3], s3);
-            s0 = fmaf(v[4], v[4], s0); s1 = fmaf(v[5], v[5], s1); s2 = fmaf(v[6], v[6], s2); s3 = fmaf(v[7], v[7], s3);
+            for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
         }
-        red[threadIdx.x] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[r] = (float)(red[0] / ((double)kVScale * (double)kVScale));
+        s0 = fmaf(v[0], v[0], s0); s1 = fmaf(v[1], v[1], s1); s2 = fmaf(v[2], v[2], s2); s3 = fmaf(v[3], v[3], s3);
+        s0 = fmaf(v[4], v[4], s0); s1 = fmaf(v[5], v[5], s1); s2 = fmaf(v[6], v[6], s2); s3 = fmaf(v[7], v[7], s3);
+    }
+    red[threadIdx.x] = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
+    if (threadIdx.x == 0) part[r * nseg + blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) row_sqnorm_h1_final_kernel(const double *__restrict__ part, int64_t n, int nseg, float *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double s = 0.0;
+    for (int i = 0; i < nseg; ++i) s += part[r * nseg + i];
+    out[r] = (float)(s / ((double)kVScale * (double)kVScale));
 }
 
 // 8 consecutive elements of a split row (k % 8 == 0) as floats (still multiplied by kVScale)
@@ -1090,6 +1103,10 @@ int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
     // the convolution kernels address one activation tensor through a 32-bit buffer descriptor: keep the largest (H x W x 64 values of 4 bytes) under 3 GiB
     const int64_t cap = (int64_t)(0xB0000000ull / ((uint64_t)H * W * 64 * 4));
     if (want > cap) want = cap;
+    // the deepest block (conv5_x: 2 column tiles x H W / 65 536 position tiles per image) should fill the 256 CUs a whole number of times:
+    // 2048 images of 64 x 64, 512 of 128 x 128, 128 of 256 x 256 (176 would leave conv5_x at 1.4 rounds)
+    const int64_t whole = (int64_t)((8ull << 20) / ((uint64_t)H * W));
+    if (l->chunk <= 0 && whole >= 1 && want >= whole) want -= want % whole;
     GL_REQUIRE(want >= 1, "gl_lpips_features: %d x %d images are too large for one pass", H, W);
     if (n < want) want = n;
     if (want <= l->ws_imgs && H == l->ws_H && W == l->ws_W) return GL_OK;
@@ -1255,7 +1272,14 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             hipLaunchKernelGGL(image_part_h1_kernel<T>, dim3((unsigned)stream_blocks(m * Dp)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D, Dp,
                                (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg);
             GL_LAUNCH_CHECK();
-            hipLaunchKernelGGL(row_sqnorm_h1_kernel, dim3((unsigned)(m < 2048 ? m : 2048)), dim3(256), 0, ctx->stream, Vc, m, K_lp, Dp, lo_seg, norms_dev + i0);
+            {
+                // partial sums go to the first activation buffer, which is free by now (m * nseg doubles)
+                const int nseg = (int)gl_ceil_div(K_lp + Dp, kNormSeg);
+                double *part = reinterpret_cast<double *>(l->ws_a);
+                hipLaunchKernelGGL(row_sqnorm_h1_part_kernel, dim3((unsigned)nseg, (unsigned)m), dim3(256), 0, ctx->stream, Vc, K_lp, Dp, lo_seg, nseg, part);
+                GL_LAUNCH_CHECK();
+                hipLaunchKernelGGL(row_sqnorm_h1_final_kernel, dim3((unsigned)gl_ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nseg, norms_dev + i0);
+            }
         } else {
             hipLaunchKernelGGL(image_part_kernel<T>, dim3((unsigned)stream_blocks(m * D)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D,
                                (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp);
