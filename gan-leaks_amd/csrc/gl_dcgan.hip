@@ -672,9 +672,12 @@ int gl_dcgan_forward(gl_dcgan *g, const float *z_dev, int64_t n, float *out_f32_
         return gl_launch_gather_conv_h3(ctx, p, phases);
     };
 
-    // balanced passes: ceil(n / passes) images each instead of full passes plus a small ragged one
+    // passes: the 4 x 4 -> 8 x 8 layer has one workgroup tile per 2 images and phase-column pair, i.e. images / 2 workgroups per launch, the
+    // next layer twice that: passes of a multiple of 512 images fill the 256 CUs a whole number of times, and only the last pass is ragged
+    // (12 496 images -- one rank's shard of 8 -- as 3 x 4096 + 208: 25 rounds of the first layer instead of the 28 of four equal passes).
+    // Workspaces smaller than that: equal passes.
     const int64_t passes = gl_ceil_div(n, g->ws_chunk);
-    const int64_t per_pass = gl_ceil_div(n, passes);
+    const int64_t per_pass = g->ws_chunk >= 512 ? g->ws_chunk - g->ws_chunk % 512 : gl_ceil_div(n, passes);
     for (int64_t i0 = 0; i0 < n; i0 += per_pass) {
         const int64_t m = (n - i0 < per_pass) ? n - i0 : per_pass;
         if (h3) {
