@@ -10,7 +10,9 @@ TAG=${1:-r02}
 QUICK=${2:-}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
-mkdir -p "$OUT" "$ROOT/profiles/$TAG"
+# the finished set goes to $OUT/final (gpurun brings back gpurun_out/ only): copy it into profiles/$TAG/ afterwards
+DEST=$OUT/final
+mkdir -p "$OUT" "$DEST"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --secondary off"
 ONE="$B --steps 1 --warmup 0 --cpu-queries 0 --check-queries 0"
@@ -38,19 +40,19 @@ echo "[profiles] pairwise kernels A/B"; python3 tools/bench_pairwise.py --varian
 if [ -z "$QUICK" ]; then
   echo "[profiles] one-rank shares of configs[3] / configs[4]"; python3 tools/bench_shard_configs.py > "$OUT/shard_configs.jsonl"
   echo "[profiles] end-to-end parity at configs[1] size"; python3 tools/auroc_delta_full.py > "$OUT/auroc_delta_full_config2.json"
-  cp "$OUT/shard_configs.jsonl" "profiles/$TAG/${TAG}_shard_configs.jsonl"
-  cp "$OUT/auroc_delta_full_config2.json" "profiles/$TAG/${TAG}_auroc_delta_full_config2.json"
+  cp "$OUT/shard_configs.jsonl" "$DEST/${TAG}_shard_configs.jsonl"
+  cp "$OUT/auroc_delta_full_config2.json" "$DEST/${TAG}_auroc_delta_full_config2.json"
 fi
-cp "$OUT/bench.json" "profiles/$TAG/${TAG}_bench.json"
-cp "$OUT/bench_under_rocprof.json" "profiles/$TAG/${TAG}_bench_under_rocprof.json"
-cp "$OUT"/trace/*/*_kernel_stats.csv "profiles/$TAG/${TAG}_bench_kernel_stats.csv"
-cp "$OUT/bench_l2lpips_under_rocprof.json" "profiles/$TAG/${TAG}_bench_l2lpips_under_rocprof.json"
-cp "$OUT"/trace_lp/*/*_kernel_stats.csv "profiles/$TAG/${TAG}_bench_l2lpips_kernel_stats.csv"
-cp "$OUT/generators.jsonl" "profiles/$TAG/${TAG}_generators.jsonl"
-cp "$OUT/pairwise_ab.jsonl" "profiles/$TAG/${TAG}_pairwise_ab.jsonl"
-python3 tools/pmc_summary.py "profiles/$TAG/pmc_traffic_default.json" "$OUT/pmc_fetch" "$OUT/pmc_write" > /dev/null
-python3 tools/pmc_summary.py "profiles/$TAG/${TAG}_pmc_sq_default.json" "$OUT/pmc_sq" > /dev/null
-python3 tools/pmc_summary.py "profiles/$TAG/pmc_traffic_l2lpips.json" "$OUT/pmc_fetch_lp" "$OUT/pmc_write_lp" > /dev/null
-python3 tools/pmc_summary.py "profiles/$TAG/${TAG}_pmc_sq_l2lpips.json" "$OUT/pmc_sq_lp" > /dev/null
-python3 tools/pmc_summary.py "profiles/$TAG/pmc_traffic_fp32.json" "$OUT/pmc_fetch_f32" "$OUT/pmc_write_f32" > /dev/null
-echo "profiles/$TAG refreshed (bench.py takes roofline.traffic from the newest profiles/r*/pmc_traffic_*.json)"
+cp "$OUT/bench.json" "$DEST/${TAG}_bench.json"
+cp "$OUT/bench_under_rocprof.json" "$DEST/${TAG}_bench_under_rocprof.json"
+cp "$OUT"/trace/*/*_kernel_stats.csv "$DEST/${TAG}_bench_kernel_stats.csv"
+cp "$OUT/bench_l2lpips_under_rocprof.json" "$DEST/${TAG}_bench_l2lpips_under_rocprof.json"
+cp "$OUT"/trace_lp/*/*_kernel_stats.csv "$DEST/${TAG}_bench_l2lpips_kernel_stats.csv"
+cp "$OUT/generators.jsonl" "$DEST/${TAG}_generators.jsonl"
+cp "$OUT/pairwise_ab.jsonl" "$DEST/${TAG}_pairwise_ab.jsonl"
+python3 tools/pmc_summary.py "$DEST/pmc_traffic_default.json" "$OUT/pmc_fetch" "$OUT/pmc_write" > /dev/null
+python3 tools/pmc_summary.py "$DEST/${TAG}_pmc_sq_default.json" "$OUT/pmc_sq" > /dev/null
+python3 tools/pmc_summary.py "$DEST/pmc_traffic_l2lpips.json" "$OUT/pmc_fetch_lp" "$OUT/pmc_write_lp" > /dev/null
+python3 tools/pmc_summary.py "$DEST/${TAG}_pmc_sq_l2lpips.json" "$OUT/pmc_sq_lp" > /dev/null
+python3 tools/pmc_summary.py "$DEST/pmc_traffic_fp32.json" "$OUT/pmc_fetch_f32" "$OUT/pmc_write_f32" > /dev/null
+echo "$DEST written: cp gpurun_out/profiles_$TAG/final/* profiles/$TAG/ (bench.py takes roofline.traffic from the newest profiles/r*/pmc_traffic_*.json)"

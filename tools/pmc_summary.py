@@ -17,7 +17,7 @@ import os
 import sys
 from collections import defaultdict
 
-FAMILIES = [("gather_conv_h3_kernel", "gather_conv"), ("gather_conv_kernel", "gather_conv_f32"), ("col2im_rgb_tanh_kernel", "convt_rgb"),
+FAMILIES = [("gather_conv_h3_kernel", "gather_conv"), ("halo_conv_h3_kernel", "gather_conv"), ("vgg_conv1_kernel", "vgg_conv1"), ("gather_conv_kernel", "gather_conv_f32"), ("col2im_rgb_tanh_kernel", "convt_rgb"),
             ("l2_prepare_kernel", "l2_prepare"), ("l2_knn_i8", "l2_knn"), ("feat_knn_h1", "feat_knn"), ("feat_knn_kernel", "feat_knn_split"),
             ("lpips_tap", "lpips_tap"), ("maxpool2", "maxpool2"), ("vgg_input", "vgg_input"), ("row_sqnorm", "row_sqnorm"), ("pixelnorm_split", "pixelnorm")]
 
