@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) image_part_kernel(const T *__restrict__ i
 // (8-bit images take only 256 values, so rounding x to ONE half gives a systematic ~1e-4 error in the L2 term; the LPIPS values do not)
 template <typename T>
 __global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict__ img, int64_t n, int64_t D, int64_t Dp, float inv_sqrt_d, char *__restrict__ V,
-                                                            int64_t ldv_bytes, int64_t off, int lo_seg)
+                                                            int64_t ldv_bytes, int64_t off, int lo_seg, int pad)
 {
     __shared__ float lut[256];
     lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
@@ -157,21 +157,21 @@ __global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict_
         row[k] = hi;
         row[hi2_seg * Dp + k] = hi;
         row[lo_seg * Dp + k] = lo;
+        if (k < pad) row[3 * Dp + k] = (_Float16)0.0f;       // the zero tail of a padded row (lp_search_pad)
     }
 }
 
 // |row|^2 of a search row (unscaled): sum over the LPIPS halves of h^2 + sum over the image part of (hi + lo)^2
 constexpr int kNormSeg = 32768;          // halves of a row per workgroup
-__global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__restrict__ V, int64_t K_lp, int64_t Dp, int lo_seg, int nseg,
+__global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__restrict__ V, int64_t ldv_bytes, int64_t K_lp, int64_t Dp, int lo_seg, int nseg,
                                                                   double *__restrict__ part)
 {
     // grid (segment, row): a 17 MB row of a 256 x 256 image is summed by 262 workgroups, not one (passes of that size have 128 rows); the
     // segmentation depends on the row length only, so a row's norm does not depend on the pass it is computed in
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     __shared__ double red[256];
-    const int64_t K1 = K_lp + 3 * Dp;
     const int64_t r = blockIdx.y;
-    const _Float16 *row = reinterpret_cast<const _Float16 *>(V + r * K1 * 2);
+    const _Float16 *row = reinterpret_cast<const _Float16 *>(V + r * ldv_bytes);
     const int64_t k0 = (int64_t)blockIdx.x * kNormSeg;
     const int64_t kend = k0 + kNormSeg < K_lp + Dp ? k0 + kNormSeg : K_lp + Dp;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1097,6 +1097,11 @@ int lp_upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
     return GL_OK;
 }
 
+// Search rows whose byte length is a multiple of 32 KiB (128 x 128 and 256 x 256 images: 2^15 x 131 and 2^17 x 131 bytes) get 64 zero halves
+// appended: with such a stride the same K slice of every row of a tile falls on the same few memory channels (measured on the pairwise kernel
+// at 256 x 256: 971 -> 1020 TFLOP/s with the pad; rows of 64 x 64 images, 2^13 x 131 bytes, do not need it).
+int64_t lp_search_pad(int64_t K_lp, int64_t Dp) { return ((K_lp + 3 * Dp) * 2) % 32768 == 0 ? 64 : 0; }
+
 int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
 {
     int64_t want = l->chunk > 0 ? l->chunk : 2048;
@@ -1150,7 +1155,8 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
     }
     const int64_t K = K_lp + D;
     const int64_t Dp = gl_ceil_div(D, 64) * 64;
-    const int64_t ldv = fmt ? (K_lp + 3 * Dp) * 2 : K * 4;        // bytes per row of V
+    const int64_t pad = fmt ? lp_search_pad(K_lp, Dp) : 0;
+    const int64_t ldv = fmt ? (K_lp + 3 * Dp + pad) * 2 : K * 4;        // bytes per row of V
     const int lo_seg = fmt == 1 ? 2 : 1;
     // per-tap coefficients sqrt(0.2 * w_c / (h*w))
     {
@@ -1270,13 +1276,13 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
         }
         if (fmt) {
             hipLaunchKernelGGL(image_part_h1_kernel<T>, dim3((unsigned)stream_blocks(m * Dp)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D, Dp,
-                               (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg);
+                               (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg, (int)pad);
             GL_LAUNCH_CHECK();
             {
                 // partial sums go to the first activation buffer, which is free by now (m * nseg doubles)
                 const int nseg = (int)gl_ceil_div(K_lp + Dp, kNormSeg);
                 double *part = reinterpret_cast<double *>(l->ws_a);
-                hipLaunchKernelGGL(row_sqnorm_h1_part_kernel, dim3((unsigned)nseg, (unsigned)m), dim3(256), 0, ctx->stream, Vc, K_lp, Dp, lo_seg, nseg, part);
+                hipLaunchKernelGGL(row_sqnorm_h1_part_kernel, dim3((unsigned)nseg, (unsigned)m), dim3(256), 0, ctx->stream, Vc, ldv, K_lp, Dp, lo_seg, nseg, part);
                 GL_LAUNCH_CHECK();
                 hipLaunchKernelGGL(row_sqnorm_h1_final_kernel, dim3((unsigned)gl_ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nseg, norms_dev + i0);
             }
@@ -1428,7 +1434,7 @@ int64_t gl_lpips_search_dim(int H, int W)
     const int64_t k = gl_lpips_feature_dim(H, W);
     if (k < 0) return -1;
     const int64_t D = 3ll * H * W;
-    return k - D + 3 * (gl_ceil_div(D, 64) * 64);
+    return k - D + 3 * (gl_ceil_div(D, 64) * 64) + lp_search_pad(k - D, gl_ceil_div(D, 64) * 64);
 }
 
 int gl_lpips_search_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev)

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--bank", type=int, default=99968)
     ap.add_argument("--feat-bank", type=int, default=25000)
     ap.add_argument("--res", type=int, default=64)
+    ap.add_argument("--k", type=int, default=0, help="halves per search row instead of the LPIPS row of --res (multiple of 64)")
+    ap.add_argument("--pad", type=int, default=0, help="extra halves per search row (row stride experiment)")
     args = ap.parse_args()
     if not (args.l2 or args.feat):
         args.l2 = args.feat = True
@@ -94,17 +96,19 @@ def main():
 
     if args.feat:
         Q, N = args.queries, args.feat_bank
-        K1 = int(lib.gl_lpips_search_dim(args.res, args.res))
+        K1 = (args.k or int(lib.gl_lpips_search_dim(args.res, args.res))) + args.pad
         g = torch.Generator(device="cuda").manual_seed(2)
         # search rows hold V * 2^14 with V ~ 1e-3..1e-1: positive halves of order 1..1000
-        bank = (torch.rand((N, K1), dtype=torch.float32, device="cuda", generator=g) * 64.0).to(torch.float16)
-        qs = (torch.rand((Q, K1), dtype=torch.float32, device="cuda", generator=g) * 64.0).to(torch.float16) if Q * K1 < 6e9 else None
-        if qs is None:
-            qs = torch.empty((Q, K1), dtype=torch.float16, device="cuda")
-            for a in range(0, Q, 1000):
-                qs[a:a + 1000] = (torch.rand((min(1000, Q - a), K1), dtype=torch.float32, device="cuda", generator=g) * 64.0).to(torch.float16)
+        def rows(n):        # filled in pieces: the fp32 temporaries of a 256 x 256 row set would not fit beside it
+            out = torch.empty((n, K1), dtype=torch.float16, device="cuda")
+            step = max(1, int(1e9 // K1))
+            for a in range(0, n, step):
+                out[a:a + step] = (torch.rand((min(step, n - a), K1), dtype=torch.float32, device="cuda", generator=g) * 64.0).to(torch.float16)
+            return out
+        bank, qs = rows(N), rows(Q)
         def sqn(x):      # |row|^2 in the units of the distance (rows hold V * 2^14)
-            return torch.cat([(x[a:a + 512].float() ** 2).sum(1) for a in range(0, len(x), 512)]) / float(2 ** 28)
+            step = max(1, int(1e9 // K1))
+            return torch.cat([(x[a:a + step].float() ** 2).sum(1) for a in range(0, len(x), step)]) / float(2 ** 28)
         bn, qn = sqn(bank), sqn(qs)
         torch.cuda.synchronize()
         keys = ctx.empty((Q,), np.uint64)
