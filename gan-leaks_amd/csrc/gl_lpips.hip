@@ -1181,6 +1181,7 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
         for (int ci = 0; ci < kNumConv; ++ci) {
             if (ci == 0) {
                 // conv1_1 reads the image itself
+                GL_REQUIRE(m * 3 * h * w < (1ll << 31), "gl_lpips_features: a pass of %lld images of %d x %d is too large for conv1_1's 32-bit offsets", (long long)m, h, w);
                 const unsigned nb = (unsigned)std::min<int64_t>(gl_ceil_div(m * h * w, 128), (int64_t)ctx->num_cu * 8);
                 if (h3)
                     hipLaunchKernelGGL((vgg_conv1_kernel<T, true>), dim3(nb), dim3(256), 0, ctx->stream, img_dev + i0 * D, (int)m, h, w, l->w[0], l->bias[0],
