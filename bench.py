@@ -341,6 +341,16 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
     roofline["avg_launch_ms"] = dominant["avg_ms"]
     roofline["launches_per_step"] = dominant["launches"] / steps
 
+    # split-fp16 stores clamp at the fp16 range and count it; the library's Python callers redo such a pass with fp32 products, this file
+    # calls the C ABI directly: a timed step that clamped anything is not a measurement of the stated arithmetic
+    n_sat = ctx.h3_saturations()
+    if world > 1:
+        t = torch.tensor([n_sat], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)        # every rank raises, or none does
+        n_sat = int(t.item())
+    if n_sat:
+        raise RuntimeError("bench: %d split-fp16 stores saturated during the timed steps; run with --gen-precision 0" % n_sat)
+
     # ---------------------------------------------------------------- parity check against the oracle (untimed)
     parity = None
     auroc = None
