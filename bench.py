@@ -174,7 +174,9 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
         lp_model.set_precision(gen_precision)
         KF_ALG = int(lib.gl_lpips_feature_dim(64, 64))          # 512 000: the contraction length the roofline is priced on
         h1 = args.feat_rows == "fp16"
-        KF = int(lib.gl_lpips_search_dim(64, 64)) if h1 else KF_ALG
+        # 8-bit images on both sides: lattice search rows (image part exact in one fp16 K segment), KF = KF_ALG = 512 000 halves
+        KF = int(lib.gl_lpips_lattice_dim(64, 64)) if h1 else KF_ALG
+        row_scale = float(lib.gl_lpips_lattice_scale(64, 64))
         row_dtype = np.float16 if h1 else np.float32
         need_gb = (n_loc + Q) * KF * np.dtype(row_dtype).itemsize / 1e9
         log("[rank %d] l2-lpips: feature vectors need %.1f GB of HBM" % (rank, need_gb))
@@ -215,14 +217,16 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
             check(lib.gl_l2_knn_i8(ctx.handle, p(bank_i8.ptr), p(bank_nrm.ptr), n_loc, lo, p(q_i8.ptr), p(q_nrm.ptr), Q, D, p(keys.ptr)))
         else:
             if h1:
-                check(lib.gl_lpips_search_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, 1, p(bank_V.ptr), p(bank_Vn.ptr)))
-                check(lib.gl_lpips_search_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, 0, p(q_V.ptr), p(q_Vn.ptr)))
+                check(lib.gl_lpips_lattice_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
+                check(lib.gl_lpips_lattice_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
             else:
                 check(lib.gl_lpips_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
                 check(lib.gl_lpips_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
             check(lib.gl_keys_init(ctx.handle, p(keys.ptr), Q))
-            knn = lib.gl_feat_knn_h1 if h1 else lib.gl_feat_knn
-            check(knn(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr)))
+            if h1:
+                check(lib.gl_feat_knn_h1_scaled(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr), row_scale))
+            else:
+                check(lib.gl_feat_knn(ctx.handle, p(bank_V.ptr), p(bank_Vn.ptr), n_loc, lo, p(q_V.ptr), p(q_Vn.ptr), Q, KF, p(keys.ptr)))
         if timed_phases is not None:
             ev[2].record()
         # the path's one exchange step: the minimum over ranks of Q packed keys (80 KB)
@@ -309,10 +313,10 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
                      conv_peak, "TFLOP/s", 1e12, 3.0 if split else 1.0,
                      "split-fp16: x = hi + lo, 3 fp16 MFMAs per product; achieved counts each product once, peak is the fp16 dense peak" if split else None),
         kernel_entry("l2_knn", 2.0 * Q * n_loc * D, "mfma", PEAK_I8_MFMA_TOPS, "TOP/s", 1e12),
-        # algorithmic length 512 000 (K_lpips + D); search rows issue 536 576 / 512 000 MFMA products per algorithmic one, split rows 3
+        # algorithmic length 512 000 (K_lpips + D); lattice search rows are exactly that long, split rows issue 3 MFMA products per algorithmic one
         kernel_entry("feat_knn", 0 if lp_model is None else 2.0 * Q * n_loc * KF_ALG, "mfma", PEAK_F16_MFMA_TFLOPS, "TFLOP/s", 1e12,
                      1.0 if lp_model is None else (KF / KF_ALG if h1 else 3.0),
-                     None if lp_model is None else ("fp16 search rows: one MFMA per LPIPS product, three for the 12 288 image values" if h1
+                     None if lp_model is None else ("fp16 lattice search rows (8-bit images): one MFMA per product, the 12 288 image values exact in fp16" if h1
                                                     else "split-fp16 contraction: 3 fp16 MFMAs per product")),
         # col2im + tanh + quantise: reads P [1024][48] fp32, writes 12288 codes per image
         kernel_entry("convt_rgb", n_loc * (1024 * 48 * 4 + 12288.0), "hbm", PEAK_HBM_GBS, "GB/s", 1e9),

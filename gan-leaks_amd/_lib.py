@@ -117,9 +117,13 @@ SIGNATURES = {
     "gl_rows_split_f32": (_i, [_p, _p, _i64, _i64, _p, _p, _p]),
     "gl_rows_knn_split": (_i, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p]),
     "gl_lpips_search_dim": (_i64, [_i, _i]),
+    "gl_lpips_lattice_dim": (_i64, [_i, _i]),
+    "gl_lpips_lattice_scale": (ctypes.c_float, [_i, _i]),
+    "gl_lpips_lattice_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_lpips_search_features_u8": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
     "gl_lpips_search_features_f32": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),
     "gl_feat_knn_h1": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p]),
+    "gl_feat_knn_h1_scaled": (_i, [_p, _p, _p, _i64, _i64, _p, _p, _i64, _i64, _p, ctypes.c_float]),
     "gl_feat_rows_dist": (_i, [_p, _p, _i64, _p, _i64, _i64, _i64, _p, _p]),
     "gl_comm_unique_id": (_i, [_p]),
     "gl_comm_init_rank": (_i, [_p, _p, _i, _i, _pp]),

@@ -236,6 +236,8 @@ def unpack_keys(ctx, keys, nq, d, kind="u8"):
 def _feature_row_bytes(ctx, model, images):
     h, w = int(images.shape[2]), int(images.shape[3])
     if model.search_rows == "fp16":
+        if getattr(images, "dtype", None) == np.uint8:               # 8-bit codes: lattice search rows (LpipsModel.features)
+            return 2 * int(ctx.lib.gl_lpips_lattice_dim(h, w))
         return 2 * int(ctx.lib.gl_lpips_search_dim(h, w))
     return 4 * int(ctx.lib.gl_lpips_feature_dim(h, w))
 
@@ -271,18 +273,32 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
                 parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath)
                          for a in range(0, len(queries), q_step)]
                 return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
-        fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=model.search_role("query"))
-        b_role = "bank" if getattr(fq, "role", None) else None
-        step = max(1, int(chunk_bytes // (fq.K * (2 if fq.role else 4))))
-        if fq.role:
-            step = _lp.preferred_bank_rows(step, fq.n)
-        keys, buf = None, None
-        for lo in range(0, n_rows, step):
-            hi = min(lo + step, n_rows)
-            buf = model.features(rows(lo, hi), index_base=base + lo, role=b_role, out=buf)     # one feature buffer, reused by every chunk
-            keys = _lp.feat_knn_keys(buf, fq, keys=keys)
-            ctx.sync()
-        return finish(keys, fq.n, fq.K, "f32")
+        raw_queries = getattr(queries, "kind", None) != "feat"
+        fq = model.features(queries, role=model.search_role("query")) if raw_queries else queries
+        # both sides must have one row layout: 8-bit codes give lattice rows, an off-lattice float chunk forces the hi / lo layout on
+        # everything (the queries are then featurised again, which needs their images)
+        for attempt in (0, 1):
+            b_role = "bank" if getattr(fq, "role", None) else None
+            step = max(1, int(chunk_bytes // (fq.K * (2 if fq.role else 4))))
+            if fq.role:
+                step = _lp.preferred_bank_rows(step, fq.n)
+            keys, buf, ok = None, None, True
+            for lo in range(0, n_rows, step):
+                hi = min(lo + step, n_rows)
+                try:
+                    buf = model.features(rows(lo, hi), index_base=base + lo, role=b_role, out=buf, fmt=getattr(fq, "fmt", None))   # one buffer for every chunk
+                except ValueError:
+                    if attempt or not raw_queries or getattr(fq, "fmt", None) != "lattice":
+                        raise
+                    ok = False
+                    break
+                keys = _lp.feat_knn_keys(buf, fq, keys=keys)
+                ctx.sync()
+            if ok:
+                return finish(keys, fq.n, fq.K, "f32")
+            del buf
+            fq = model.features(queries, role="query", fmt="hilo")
+        raise AssertionError("unreachable")
 
     # 'l2': every chunk must take the same arithmetic path.  Exact integers unless the queries or some chunk are off the 8-bit lattice;
     # then everything is redone on the fixed-order fp32 path (what the resident form does for such inputs).
@@ -365,9 +381,20 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
             bank = bank[:n_rows]
 
     if distance == "l2-lpips":
-        fb = bank if prepared else model.features(bank, role=model.search_role("bank"))
+        q_feat = getattr(queries, "kind", None) == "feat"
+        fb = bank if prepared else model.features(bank, role=model.search_role("bank"), fmt=getattr(queries, "fmt", None) if q_feat else None)
         q_role = "query" if getattr(fb, "role", None) else None          # queries follow the bank's row format
-        fq = queries if getattr(queries, "kind", None) == "feat" else model.features(queries, role=q_role)
+        if q_feat:
+            fq = queries
+        else:
+            try:
+                fq = model.features(queries, role=q_role, fmt=getattr(fb, "fmt", None))
+            except ValueError:
+                # off-lattice float queries against lattice rows of an 8-bit bank: both sides in the hi / lo layout instead
+                if prepared or getattr(fb, "fmt", None) != "lattice":
+                    raise
+                fb = model.features(bank, role="bank", fmt="hilo")
+                fq = model.features(queries, role="query", fmt="hilo")
         keys = _lp.feat_knn_keys(fb, fq, n_rows)
         if reduce_fn is not None:
             keys = reduce_fn(keys)

@@ -79,17 +79,17 @@ def check_args(args):
 _bank_cache = {"key": None, "bank": None}
 
 
-def _cached_bank(syn_imgs, n_rows, loss):
+def _cached_bank(syn_imgs, n_rows, loss, fmt=None):
     """custom_knn is called once per query with the same bank (fbb.py:156-159): prepare it once
     (int8 rows for 'l2'; VGG16/LPIPS feature vectors for 'l2-lpips')."""
     if isinstance(syn_imgs, Bank) or getattr(syn_imgs, "kind", None) == "feat":
         return syn_imgs
     ptr = syn_imgs.data_ptr() if hasattr(syn_imgs, "data_ptr") else (
         syn_imgs.ctypes.data if isinstance(syn_imgs, np.ndarray) else id(syn_imgs))
-    key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows, loss.distance, id(loss.lpips_model))
+    key = (id(syn_imgs), ptr, tuple(syn_imgs.shape), n_rows, loss.distance, id(loss.lpips_model), fmt)
     if _bank_cache["key"] != key:
         if loss.distance == "l2-lpips":
-            _bank_cache["bank"] = loss.lpips_model.features(syn_imgs[:n_rows], role=loss.lpips_model.search_role("bank"))
+            _bank_cache["bank"] = loss.lpips_model.features(syn_imgs[:n_rows], role=loss.lpips_model.search_role("bank"), fmt=fmt)
         else:
             _bank_cache["bank"] = Bank.from_images(syn_imgs[:n_rows], keep_u8=True)
         _bank_cache["key"] = key
@@ -127,9 +127,18 @@ def custom_knn(syn_imgs, sample, loss, args):
     n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
     if n_rows == 0:
         raise ValueError("torch.cat(): expected a non-empty list of Tensors")   # what fbb.py:83 raises
-    bank = _cached_bank(syn_imgs, n_rows, loss)
     q = sample.unsqueeze(0) if hasattr(sample, "unsqueeze") else np.asarray(sample)[None]
-    dist, idx = attack(q, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=loss.lpips_model)
+    bank = _cached_bank(syn_imgs, n_rows, loss, _bank_cache.get("fmt") if _bank_cache.get("fmt_for") == id(syn_imgs) else None)
+    try:
+        dist, idx = attack(q, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=loss.lpips_model)
+    except ValueError:
+        # an off-lattice float query against the lattice search rows of an 8-bit bank: rebuild the cached rows in the layout that takes
+        # any float image (LpipsModel.features), and keep using it for this bank
+        if getattr(bank, "fmt", None) != "lattice":
+            raise
+        _bank_cache["fmt"], _bank_cache["fmt_for"] = "hilo", id(syn_imgs)
+        bank = _cached_bank(syn_imgs, n_rows, loss, "hilo")
+        dist, idx = attack(q, bank, distance=distance, batch_size=args.BATCH_SIZE, lpips=loss.lpips_model)
     return float(dist[0]), int(idx[0])
 
 

@@ -61,6 +61,14 @@ __global__ void __launch_bounds__(256) maxpool2_nhwc_kernel(const float *__restr
 
 constexpr float kVScale = 16384.0f;     // V is stored as halves of V * 2^14 (values of 1e-4 .. 1e-1 stay out of the fp16 subnormals)
 
+// "Lattice" search rows (8-bit images only): a pixel 2 c / 255 - 1 is m / 255 with m = 2 c - 255 an odd integer of 9 bits, so with the row
+// scale u = 255 sqrt(D) 2^e the image part of V * u is m * 2^e -- EXACT in one fp16, no hi / lo pair, one K segment of D halves instead of
+// three.  e is chosen so that u lies in (2^13, 2^14] like kVScale (u = 14 133.7 for every square power-of-two image size); the LPIPS part
+// is V * u rounded to fp16 as before.  The L2 term of the distance is then exact up to the fp32 accumulation, and the contraction is
+// K_lp + D long (the algorithmic length) instead of K_lp + 3 D.
+static inline int lp_lattice_exp(int64_t D) { return (int)std::floor(std::log2(16384.0 / (255.0 * std::sqrt((double)D)))); }
+static inline double lp_lattice_scale(int64_t D) { return 255.0 * std::sqrt((double)D) * std::ldexp(1.0, lp_lattice_exp(D)); }
+
 // element k of a split-layout row -> byte offset of its hi half (lo half: +64)
 __device__ __forceinline__ int64_t split_off(int64_t k) { return (k >> 5) * 128 + (k & 31) * 2; }
 
@@ -161,6 +169,19 @@ __global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict_
     }
 }
 
+// image part of a lattice search row: (2 code - 255) * 2^e, exact in fp16; zero padded to Dp + pad
+__global__ void __launch_bounds__(256) image_part_lattice_kernel(const uint8_t *__restrict__ img, int64_t n, int64_t D, int64_t Dp_pad, float two_e,
+                                                                 char *__restrict__ V, int64_t ldv_bytes, int64_t off)
+{
+    const int64_t total = n * Dp_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t im = i / Dp_pad;
+        const int64_t k = i - im * Dp_pad;
+        const float v = k < D ? (float)(2 * (int)img[im * D + k] - 255) * two_e : 0.0f;
+        reinterpret_cast<_Float16 *>(V + im * ldv_bytes)[off + k] = (_Float16)v;
+    }
+}
+
 // |row|^2 of a search row (unscaled): sum over the LPIPS halves of h^2 + sum over the image part of (hi + lo)^2
 constexpr int kNormSeg = 32768;          // halves of a row per workgroup
 __global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__restrict__ V, int64_t ldv_bytes, int64_t K_lp, int64_t Dp, int lo_seg, int nseg,
@@ -180,7 +201,7 @@ __global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__r
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
-        if (k >= K_lp) {
+        if (lo_seg > 0 && k >= K_lp) {
             const h8 l = *reinterpret_cast<const h8 *>(row + k + lo_seg * Dp);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
@@ -197,13 +218,13 @@ __global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__r
     if (threadIdx.x == 0) part[r * nseg + blockIdx.x] = red[0];
 }
 
-__global__ void __launch_bounds__(256) row_sqnorm_h1_final_kernel(const double *__restrict__ part, int64_t n, int nseg, float *__restrict__ out)
+__global__ void __launch_bounds__(256) row_sqnorm_h1_final_kernel(const double *__restrict__ part, int64_t n, int nseg, double inv_scale2, float *__restrict__ out)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
     double s = 0.0;
     for (int i = 0; i < nseg; ++i) s += part[r * nseg + i];
-    out[r] = (float)(s / ((double)kVScale * (double)kVScale));
+    out[r] = (float)(s * inv_scale2);
 }
 
 // 8 consecutive elements of a split row (k % 8 == 0) as floats (still multiplied by kVScale)
@@ -795,7 +816,7 @@ constexpr int GT = 256, GOPER = GT * FROW;
 __global__ void __launch_bounds__(512, 2)
 feat_knn_h1_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                    const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
-                   unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+                   unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, float inv_s2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][bank 32 KiB | query 32 KiB]
     const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
@@ -870,7 +891,6 @@ feat_knn_h1_kernel(const char *__restrict__ bank, const float *__restrict__ bank
     }
 
     // epilogue: C tile 16x16: column (query) = lane & 15, row (bank) = 4 * (lane >> 4) + reg
-    const float inv_s2 = 1.0f / (kVScale * kVScale);
     const int64_t nbase = n0 + wn * 128 + fk * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -900,7 +920,7 @@ template <int SPREAD>
 __global__ void __launch_bounds__(512, 2)
 feat_knn_h1p_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                     const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
-                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles)
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, float inv_s2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const unsigned id = gl_xcd_remap(blockIdx.x, (unsigned)q_tiles * (unsigned)n_tiles);
@@ -929,7 +949,6 @@ feat_knn_h1p_kernel(const char *__restrict__ bank, const float *__restrict__ ban
     gl_pair256::mainloop<v8h, 0, SPREAD>(sa, sb, K1 / 64, smem, acc, wave, lane,
                               [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); });
 
-    const float inv_s2 = 1.0f / (kVScale * kVScale);
     const int64_t nbase = n0 + wn * 128 + fk * 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -987,7 +1006,7 @@ __device__ __forceinline__ void cluster_meet(unsigned *counter, unsigned target)
 __global__ void __launch_bounds__(512, 2)
 feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                     const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
-                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, int members)
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, int members, float inv_s2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int cluster = blockIdx.x & (kClusters - 1), member = blockIdx.x >> 3;
@@ -1000,7 +1019,6 @@ feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ ban
     const int sup_n = (n_tiles + kSuperN - 1) / kSuperN, sup_q = (q_tiles + kSuperQ - 1) / kSuperQ;
     const int64_t nk = K1 / 64;
     const int nseg = (int)((nk + kSegSlices - 1) / kSegSlices);
-    const float inv_s2 = 1.0f / (kVScale * kVScale);
     v4f *my_tot = totals + (size_t)wave * 32 * 64 + lane;
     unsigned episode = 0;
 
@@ -1100,7 +1118,7 @@ int lp_upload(gl_ctx *ctx, float **dev, const std::vector<float> &host)
 // Search rows whose byte length is a multiple of 32 KiB (128 x 128 and 256 x 256 images: 2^15 x 131 and 2^17 x 131 bytes) get 64 zero halves
 // appended: with such a stride the same K slice of every row of a tile falls on the same few memory channels (measured on the pairwise kernel
 // at 256 x 256: 971 -> 1020 TFLOP/s with the pad; rows of 64 x 64 images, 2^13 x 131 bytes, do not need it).
-int64_t lp_search_pad(int64_t K_lp, int64_t Dp) { return ((K_lp + 3 * Dp) * 2) % 32768 == 0 ? 64 : 0; }
+int64_t lp_search_pad(int64_t K_lp, int64_t Dp, int img_segs = 3) { return ((K_lp + img_segs * Dp) * 2) % 32768 == 0 ? 64 : 0; }
 
 int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
 {
@@ -1155,15 +1173,21 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
     }
     const int64_t K = K_lp + D;
     const int64_t Dp = gl_ceil_div(D, 64) * 64;
-    const int64_t pad = fmt ? lp_search_pad(K_lp, Dp) : 0;
-    const int64_t ldv = fmt ? (K_lp + 3 * Dp + pad) * 2 : K * 4;        // bytes per row of V
-    const int lo_seg = fmt == 1 ? 2 : 1;
+    // fmt 3: lattice search rows (8-bit images): K_lp + Dp halves, image part exact, row scale lp_lattice_scale(D) instead of kVScale
+    const bool lattice = fmt == 3;
+    GL_REQUIRE(!lattice || sizeof(T) == 1, "gl_lpips_features: lattice search rows need 8-bit images");
+    const int img_segs = lattice ? 1 : 3;
+    const int64_t pad = fmt ? lp_search_pad(K_lp, Dp, img_segs) : 0;
+    const int64_t ldv = fmt ? (K_lp + img_segs * Dp + pad) * 2 : K * 4;        // bytes per row of V
+    const int lo_seg = lattice ? 0 : (fmt == 1 ? 2 : 1);
+    const double row_scale = lattice ? (double)(float)lp_lattice_scale(D) : (double)kVScale;      // the float the search kernel is given
     // per-tap coefficients sqrt(0.2 * w_c / (h*w))
     {
         std::vector<float> coef;
         int h = H, w = W;
         for (int t = 0; t < 5; ++t) {
-            for (int c = 0; c < kTapC[t]; ++c) coef.push_back((float)std::sqrt(0.2 * (double)l->lin_host[t][c] / ((double)h * w)));
+            // the tap kernels multiply by kVScale; rows of another scale get the ratio here
+            for (int c = 0; c < kTapC[t]; ++c) coef.push_back((float)(std::sqrt(0.2 * (double)l->lin_host[t][c] / ((double)h * w)) * (row_scale / (double)kVScale)));
             h /= 2; w /= 2;
         }
         rc = lp_upload(ctx, &l->ws_coef, coef);
@@ -1276,8 +1300,14 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             }
         }
         if (fmt) {
-            hipLaunchKernelGGL(image_part_h1_kernel<T>, dim3((unsigned)stream_blocks(m * Dp)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D, Dp,
-                               (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg, (int)pad);
+            if (lattice) {
+                if constexpr (sizeof(T) == 1)
+                    hipLaunchKernelGGL(image_part_lattice_kernel, dim3((unsigned)stream_blocks(m * (Dp + pad))), dim3(256), 0, ctx->stream,
+                                       reinterpret_cast<const uint8_t *>(img_dev) + i0 * D, m, D, Dp + pad, (float)std::ldexp(1.0, lp_lattice_exp(D)), Vc, ldv, K_lp);
+            } else {
+                hipLaunchKernelGGL(image_part_h1_kernel<T>, dim3((unsigned)stream_blocks(m * Dp)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D, Dp,
+                                   (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg, (int)pad);
+            }
             GL_LAUNCH_CHECK();
             {
                 // partial sums go to the first activation buffer, which is free by now (m * nseg doubles)
@@ -1285,7 +1315,8 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 double *part = reinterpret_cast<double *>(l->ws_a);
                 hipLaunchKernelGGL(row_sqnorm_h1_part_kernel, dim3((unsigned)nseg, (unsigned)m), dim3(256), 0, ctx->stream, Vc, ldv, K_lp, Dp, lo_seg, nseg, part);
                 GL_LAUNCH_CHECK();
-                hipLaunchKernelGGL(row_sqnorm_h1_final_kernel, dim3((unsigned)gl_ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nseg, norms_dev + i0);
+                hipLaunchKernelGGL(row_sqnorm_h1_final_kernel, dim3((unsigned)gl_ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nseg,
+                                   1.0 / (row_scale * row_scale), norms_dev + i0);
             }
         } else {
             hipLaunchKernelGGL(image_part_kernel<T>, dim3((unsigned)stream_blocks(m * D)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D,
@@ -1438,6 +1469,22 @@ int64_t gl_lpips_search_dim(int H, int W)
     return k - D + 3 * (gl_ceil_div(D, 64) * 64) + lp_search_pad(k - D, gl_ceil_div(D, 64) * 64);
 }
 
+int64_t gl_lpips_lattice_dim(int H, int W)
+{
+    const int64_t k = gl_lpips_feature_dim(H, W);
+    if (k < 0) return -1;
+    const int64_t D = 3ll * H * W, Dp = gl_ceil_div(D, 64) * 64;
+    return k - D + Dp + lp_search_pad(k - D, Dp, 1);
+}
+
+float gl_lpips_lattice_scale(int H, int W) { return H > 0 && W > 0 ? (float)lp_lattice_scale(3ll * H * W) : 0.0f; }
+
+int gl_lpips_lattice_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, void *V16_dev, float *norms_dev)
+{
+    gl_make_current(l ? l->ctx : nullptr);
+    return lpips_features_impl<uint8_t>(l, img_u8_dev, n, H, W, V16_dev, norms_dev, 3);
+}
+
 int gl_lpips_search_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev)
 {
     gl_make_current(l ? l->ctx : nullptr);
@@ -1452,11 +1499,13 @@ int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t 
     return lpips_features_impl<float>(l, img_f32_dev, n, H, W, V16_dev, norms_dev, 1 + role);
 }
 
-int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
-                   const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev)
+int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
+                          const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev, float row_scale)
 {
     gl_make_current(ctx);
     GL_REQUIRE(ctx && n_rows >= 0 && nq >= 0 && K1 > 0 && K1 % 64 == 0, "gl_feat_knn_h1: bad sizes (K1 must be a multiple of 64)");
+    GL_REQUIRE(row_scale > 0.0f, "gl_feat_knn_h1: the row scale must be positive");
+    const float inv_s2 = 1.0f / (row_scale * row_scale);
     GL_REQUIRE(index_base >= 0 && index_base + n_rows <= 0xFFFFFFFFll, "gl_feat_knn_h1: global index does not fit 32 bits");
     if (n_rows == 0 || nq == 0) return GL_OK;
     GL_REQUIRE(bank_V16_dev && bank_norm_dev && query_V16_dev && query_norm_dev && keys_dev, "gl_feat_knn_h1: NULL device pointer");
@@ -1488,16 +1537,22 @@ int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm
         GL_HIP(hipMemsetAsync(ctx->pair_scratch, 0, 4096, ctx->stream));         // the cluster counters
         hipLaunchKernelGGL(feat_knn_h1c_kernel, dim3((unsigned)(kClusters * members)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
                            bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
-                           reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members);
+                           reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members, inv_s2);
         GL_LAUNCH_CHECK();
         return GL_OK;
     }
     auto kern = variant == 0 ? feat_knn_h1_kernel : variant == 4 ? feat_knn_h1p_kernel<4> : variant == 2 ? feat_knn_h1p_kernel<1> : feat_knn_h1p_kernel<8>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(q_tiles * n_tiles)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev), bank_norm_dev, n_rows,
                        index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
-                       (int)n_tiles);
+                       (int)n_tiles, inv_s2);
     GL_LAUNCH_CHECK();
     return GL_OK;
+}
+
+int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
+                   const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev)
+{
+    return gl_feat_knn_h1_scaled(ctx, bank_V16_dev, bank_norm_dev, n_rows, index_base, query_V16_dev, query_norm_dev, nq, K1, keys_dev, kVScale);
 }
 
 int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const float *query_V_dev,
@@ -1581,7 +1636,7 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
 {
     gl_make_current(ctx);
     GL_REQUIRE(ctx && l && l->ctx == ctx && n_bank >= 0 && nq >= 0 && batch_size > 0, "gl_fbb_knn_lpips_host: bad argument");
-    const int64_t K1 = gl_lpips_search_dim(H, W);
+    const int64_t K1 = gl_lpips_lattice_dim(H, W);          // 8-bit images on both sides: lattice search rows
     GL_REQUIRE(K1 > 0, "gl_fbb_knn_lpips_host: H, W must be multiples of 16, got %dx%d", H, W);
     const int64_t n_eff = (n_bank / batch_size) * batch_size;
     if (n_eff == 0) {
@@ -1609,12 +1664,12 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
         int64_t sat = 0;
         int r = gl_ctx_h3_saturations(ctx, &sat);                      // clear what earlier calls on this context left behind
         if (r != GL_OK) return r;
-        r = gl_lpips_search_features_u8(l, raw, n, H, W, role, V, norms);
+        r = gl_lpips_lattice_features_u8(l, raw, n, H, W, V, norms);
         if (r != GL_OK || l->precision == 0) return r;
         r = gl_ctx_h3_saturations(ctx, &sat);
         if (r != GL_OK || sat == 0) return r;
         l->precision = 0;
-        return gl_lpips_search_features_u8(l, raw, n, H, W, role, V, norms);
+        return gl_lpips_lattice_features_u8(l, raw, n, H, W, V, norms);
     };
 #define GL_TRY(e) do { rc = (e); if (rc != GL_OK) goto done; } while (0)
     GL_TRY(gl_malloc(ctx, (size_t)((chunk > nq ? chunk : nq) * D), (void **)&raw));
@@ -1633,7 +1688,7 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
         GL_TRY(gl_ctx_sync(ctx));                                  // raw is reused
         GL_TRY(gl_memcpy_h2d(ctx, raw, bank_u8_host + lo * D, (size_t)(m * D)));
         GL_TRY(features(m, 1, bV, bn));
-        GL_TRY(gl_feat_knn_h1(ctx, bV, bn, m, lo, qV, qn, nq, K1, keys));
+        GL_TRY(gl_feat_knn_h1_scaled(ctx, bV, bn, m, lo, qV, qn, nq, K1, keys, gl_lpips_lattice_scale(H, W)));
     }
     GL_TRY(gl_keys_unpack_f32(ctx, keys, nq, dist, idx));
     GL_TRY(gl_memcpy_d2h(ctx, dist_host, dist, (size_t)nq * 4));

@@ -34,13 +34,20 @@ def _np(v):
 class FeatureBank:
     """V rows + |V|^2 of a set of images, resident in HBM (gl_lpips_features_*)."""
 
-    def __init__(self, ctx, V, norms, n, K, K_lp, index_base=0, role=None):
+    def __init__(self, ctx, V, norms, n, K, K_lp, index_base=0, role=None, fmt=None, scale=16384.0):
         self.ctx, self.V, self.norms, self.n, self.K, self.K_lp = ctx, V, norms, int(n), int(K), int(K_lp)
         self.index_base = int(index_base)
         self.kind = "feat"
-        # None: split rows (hi + lo halves of every value; any use).  'query' / 'bank': search rows (one half per LPIPS value,
-        # K = gl_lpips_search_dim halves), usable only as the two sides of feat_knn_keys
+        # None: split rows (hi + lo halves of every value; any use).  'query' / 'bank': search rows (one half per LPIPS value),
+        # usable only as the two sides of feat_knn_keys.  Search rows come in two layouts (`fmt`):
+        #   'lattice' -- 8-bit images: the image part is the exact fp16 integer (2 code - 255) * 2^e, one K segment, K =
+        #                gl_lpips_lattice_dim halves, row scale gl_lpips_lattice_scale; queries and bank rows look the same
+        #   'hilo'    -- any float image: the image part as hi / lo halves in three K segments ([hi|hi|lo] for queries, [hi|lo|hi]
+        #                for bank rows), K = gl_lpips_search_dim halves, row scale 2^14
+        # both sides of a search must have the same layout.
         self.role = role
+        self.fmt = fmt if role is not None else None
+        self.scale = float(scale)
 
     def __len__(self):
         return self.n
@@ -114,11 +121,15 @@ class LpipsModel:
             raise ValueError("LpipsModel.search_rows must be 'fp16' or 'split', got %r" % (self.search_rows,))
         return role if self.search_rows == "fp16" else None
 
-    def features(self, images, index_base=0, role=None, out=None):
+    def features(self, images, index_base=0, role=None, out=None, fmt=None):
         """images [n,3,H,W] (u8, or float in [-1,1]) -> FeatureBank.  role None: split rows; 'query' / 'bank': search rows.
-        out: a FeatureBank of the same role and image size with at least n rows whose buffers are overwritten (streamed banks reuse one)."""
+        fmt (search rows only): None = 'lattice' when the images are 8-bit codes (u8, or floats on the 8-bit lattice), else 'hilo';
+        'hilo' / 'lattice' force one (ValueError if 'lattice' is asked for off-lattice floats) -- the two sides of a search must agree.
+        out: a FeatureBank of the same role, layout and image size with at least n rows whose buffers are overwritten (streamed banks reuse one)."""
         if role not in (None, "query", "bank"):
             raise ValueError("role must be None, 'query' or 'bank', got %r" % (role,))
+        if fmt not in (None, "hilo", "lattice"):
+            raise ValueError("fmt must be None, 'hilo' or 'lattice', got %r" % (fmt,))
         if not self._loaded:
             raise RuntimeError("LpipsModel: weights not loaded")
         ctx = self.ctx
@@ -130,10 +141,23 @@ class LpipsModel:
         if K < 0:
             raise ValueError("LPIPS path needs H and W to be multiples of 16, got %dx%d" % (H, W))
         rows = _to_device_rows(ctx, images)
-        K1 = int(ctx.lib.gl_lpips_search_dim(H, W)) if role is not None else K
+        if rows.dtype == np.float32:
+            u8, bad = encode_if_lattice(ctx, rows)
+            if bad == 0:
+                rows = u8
+        u8 = rows.dtype == np.uint8
+        if role is not None:
+            if fmt == "lattice" and not u8:
+                raise ValueError("lattice search rows need 8-bit images; these floats are off the lattice")
+            fmt = fmt or ("lattice" if u8 else "hilo")
+        else:
+            fmt = None
+        lattice = fmt == "lattice"
+        K1 = K if role is None else int(ctx.lib.gl_lpips_lattice_dim(H, W) if lattice else ctx.lib.gl_lpips_search_dim(H, W))
+        scale = float(ctx.lib.gl_lpips_lattice_scale(H, W)) if lattice else 16384.0
         if out is not None:
-            if getattr(out, "role", None) != role or out.K != K1 or out.V.shape[0] < n:
-                raise ValueError("features(out=...): buffer of another role / image size, or too small")
+            if getattr(out, "role", None) != role or getattr(out, "fmt", None) != fmt or out.K != K1 or out.V.shape[0] < n:
+                raise ValueError("features(out=...): buffer of another role / layout / image size, or too small")
             V, norms = out.V, out.norms
         elif role is None:
             V = ctx.empty((max(n, 1), K), np.float32)
@@ -142,15 +166,13 @@ class LpipsModel:
             V = ctx.empty((max(n, 1), K1), np.float16)
             norms = ctx.empty((max(n, 1),), np.float32)
         r = 0 if role == "query" else 1
-        if rows.dtype == np.float32:
-            u8, bad = encode_if_lattice(ctx, rows)
-            if bad == 0:
-                rows = u8
+
         def run():
-            u8 = rows.dtype == np.uint8
             if role is None:
                 fn = ctx.lib.gl_lpips_features_u8 if u8 else ctx.lib.gl_lpips_features_f32
                 check(fn(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
+            elif lattice:
+                check(ctx.lib.gl_lpips_lattice_features_u8(self._handle, _p(rows.ptr), n, H, W, _p(V.ptr), _p(norms.ptr)))
             else:
                 fn = ctx.lib.gl_lpips_search_features_u8 if u8 else ctx.lib.gl_lpips_search_features_f32
                 check(fn(self._handle, _p(rows.ptr), n, H, W, r, _p(V.ptr), _p(norms.ptr)))
@@ -161,7 +183,7 @@ class LpipsModel:
             self.set_precision(0)
             run()
         if role is not None:
-            return FeatureBank(ctx, V, norms, n, K1, K - 3 * H * W, index_base, role)
+            return FeatureBank(ctx, V, norms, n, K1, K - 3 * H * W, index_base, role, fmt, scale)
         return FeatureBank(ctx, V, norms, n, K, K - 3 * H * W, index_base)
 
 
@@ -200,17 +222,25 @@ def preferred_bank_rows(max_rows, n_queries):
 
 def feat_knn_keys(bank, queries, n_rows=None, keys=None):
     ctx = bank.ctx
+    roles = (getattr(bank, "role", None), getattr(queries, "role", None))
+    fmts = (getattr(bank, "fmt", None), getattr(queries, "fmt", None))
+    if fmts[0] != fmts[1]:
+        raise ValueError("the two sides of a search have different row layouts: %r vs %r (LpipsModel.features(..., fmt=...))" % fmts)
     if queries.K != bank.K:
         raise ValueError("feature lengths differ: %d vs %d" % (queries.K, bank.K))
-    roles = (getattr(bank, "role", None), getattr(queries, "role", None))
-    if roles not in ((None, None), ("bank", "query")):
+    if fmts[0] != "lattice" and roles not in ((None, None), ("bank", "query")):
         raise ValueError("feat_knn_keys needs two split FeatureBanks or search rows of roles ('bank', 'query'); got %r" % (roles,))
+    if fmts[0] == "lattice" and None in roles:
+        raise ValueError("feat_knn_keys: lattice rows on one side, split rows on the other")
     n_rows = bank.n if n_rows is None else int(n_rows)
     if keys is None:
         keys = ctx.empty((max(queries.n, 1),), np.uint64)
         check(ctx.lib.gl_keys_init(ctx.handle, _p(keys.ptr), queries.n))
-    fn = ctx.lib.gl_feat_knn_h1 if roles[0] else ctx.lib.gl_feat_knn
-    check(fn(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
+    if roles[0]:
+        check(ctx.lib.gl_feat_knn_h1_scaled(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
+                                            _p(queries.norms.ptr), queries.n, bank.K, _p(keys.ptr), bank.scale))
+    else:
+        check(ctx.lib.gl_feat_knn(ctx.handle, _p(bank.V.ptr), _p(bank.norms.ptr), n_rows, bank.index_base, _p(queries.V.ptr),
                                   _p(queries.norms.ptr), queries.n, bank.K, _p(keys.ptr)))
     return keys
 

@@ -278,7 +278,19 @@ int gl_feat_knn(gl_ctx *ctx, const float *bank_V_dev, const float *bank_norm_dev
 int64_t gl_lpips_search_dim(int H, int W);
 int gl_lpips_search_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev);
 int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t n, int H, int W, int role, void *V16_dev, float *norms_dev);
-/* gl_feat_knn on search rows: same keys, one fp16 MFMA per product, 256 x 256 tiles.  K1 = gl_lpips_search_dim. */
+/* Lattice search rows, for 8-bit images on BOTH sides of the search (what fbb reads from PNG files, utils.py:60-84): a pixel 2 c / 255 - 1
+ * is (2 c - 255) / 255, so with the row scale u = gl_lpips_lattice_scale(H, W) = 255 sqrt(3 H W) 2^e the image part of a row is the exact
+ * fp16 integer (2 c - 255) 2^e: one K segment instead of the three of the hi / lo form, row length gl_lpips_lattice_dim(H, W) =
+ * K_lpips + 3 H W halves (512 000 at 64 x 64), the L2 term exact up to the fp32 accumulation.  Queries and bank rows have the same
+ * layout.  Search with gl_feat_knn_h1_scaled(..., K1 = gl_lpips_lattice_dim, row_scale = gl_lpips_lattice_scale). */
+int64_t gl_lpips_lattice_dim(int H, int W);
+float gl_lpips_lattice_scale(int H, int W);
+int gl_lpips_lattice_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, void *V16_dev, float *norms_dev);
+
+/* gl_feat_knn on search rows: same keys, one fp16 MFMA per product, 256 x 256 tiles.  K1 = gl_lpips_search_dim.
+ * gl_feat_knn_h1_scaled: rows stored as V * row_scale (gl_feat_knn_h1: 2^14, the scale of gl_lpips_search_features_*). */
+int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
+                          const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev, float row_scale);
 int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,
                    const float *query_norm_dev, int64_t nq, int64_t K1, uint64_t *keys_dev);
 /* mean((y-x)^2) + argmin for ARBITRARY fp32 rows on the matrix cores (an alternative to the bit-reproducible VALU path gl_l2_knn_f32; ~15-60x

@@ -345,3 +345,37 @@ def test_feature_rows_do_not_depend_on_the_pass_size(role, gl, synth, lin):
     for per_pass in (96, 288):
         assert np.array_equal(rows[16][0].view(np.uint8), rows[per_pass][0].view(np.uint8)), "V differs between passes of 16 and %d images" % per_pass
         assert np.array_equal(rows[16][1], rows[per_pass][1])
+
+
+def test_lattice_and_hilo_search_rows_agree(gl, synth, model, lin, oracle):
+    """8-bit images give lattice search rows (image part exact in one fp16 K segment); the hi / lo layout takes any float image.  Same
+    neighbours, distances within the fp16 rounding of the LPIPS part; a mixed pair (8-bit bank, off-lattice float queries) is searched in
+    the hi / lo layout on both sides, and mismatched layouts are refused."""
+    import lpips_oracle
+    from ganleaks_amd.lpips import feat_knn_keys
+    from ganleaks_amd.attack import unpack_keys
+    case = synth.attack_case(97, 40, 3, 3, 32, sigma=20.0)
+    bank, q = case["bank"], np.concatenate([case["pos"], case["neg"]])
+    ctx = gl.Context.get()
+    res = {}
+    for fmt in ("lattice", "hilo"):
+        fb, fq = model.features(bank, role="bank", fmt=fmt), model.features(q, role="query", fmt=fmt)
+        assert fb.fmt == fmt and fq.fmt == fmt
+        res[fmt] = unpack_keys(ctx, feat_knn_keys(fb, fq), fq.n, fq.K, "f32")
+    lib = ctx.lib
+    assert model.features(q, role="query").fmt == "lattice" and model.features(q, role="query").K == int(lib.gl_lpips_lattice_dim(32, 32))
+    assert int(lib.gl_lpips_lattice_dim(32, 32)) == int(lib.gl_lpips_feature_dim(32, 32))          # K_lpips + D: the algorithmic length
+    assert np.array_equal(res["lattice"][1], res["hilo"][1]) and np.abs(res["lattice"][0] - res["hilo"][0]).max() < 2e-6
+    sd = synth.vgg16_state_dict(7)
+    od, oi, _ = lpips_oracle.knn_l2_lpips(sd, [lin["lin%d" % i] for i in range(5)], oracle.dequantize_u8(bank), oracle.dequantize_u8(q), 8)
+    assert np.array_equal(res["lattice"][1], oi) and np.abs(res["lattice"][0] - od).max() < 5e-6
+    # mixed: the bank stays 8-bit, the queries leave the lattice
+    qf = np.clip(oracle.dequantize_u8(q) + np.random.default_rng(1).normal(0, 0.01, q.shape).astype(np.float32), -1, 1)
+    od, oi, _ = lpips_oracle.knn_l2_lpips(sd, [lin["lin%d" % i] for i in range(5)], oracle.dequantize_u8(bank), qf, 8)
+    for kw in ({}, {"chunk_bytes": 3 * 2 * int(lib.gl_lpips_search_dim(32, 32))}):       # resident, and streamed in chunks of 3 rows
+        d, i = gl.attack(qf, bank, distance="l2-lpips", batch_size=8, lpips=model, **kw)
+        assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
+    with pytest.raises(ValueError):
+        model.features(qf, role="query", fmt="lattice")
+    with pytest.raises(ValueError):
+        feat_knn_keys(model.features(bank, role="bank", fmt="hilo"), model.features(q, role="query"))

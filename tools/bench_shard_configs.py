@@ -62,7 +62,7 @@ def main():
         ctx.prof_enable(False)
         prof = ctx.prof_read()
         ctx.prof_reset()
-        K1 = int(ctx.lib.gl_lpips_search_dim(256, 256))
+        K1 = int(ctx.lib.gl_lpips_lattice_dim(256, 256))          # 8-bit images on both sides: lattice search rows
         K_alg = int(ctx.lib.gl_lpips_feature_dim(256, 256))
         knn_ms, knn_n = prof["feat_knn"]
         conv_ms, conv_n = prof["gather_conv"]
