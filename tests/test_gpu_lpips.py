@@ -328,23 +328,25 @@ def test_host_one_call_falls_back_when_split_fp16_saturates(gl, synth, lin):
     assert np.array_equal(i1, i0) and np.abs(d1 - d0).max() < 5e-6
 
 
-@pytest.mark.parametrize("role", ["bank", None])
-def test_feature_rows_do_not_depend_on_the_pass_size(role, gl, synth, lin):
+@pytest.mark.parametrize("role,res,n,passes", [("bank", 64, 288, (16, 96, 288)), (None, 64, 288, (16, 96, 288)), ("bank", 256, 20, (4, 20))])
+def test_feature_rows_do_not_depend_on_the_pass_size(role, res, n, passes, gl, synth, lin):
     """The images-per-pass setting picks the kernels: small passes run every tap as its own kernel behind the tap-gather convolution,
-    64+ images put conv1_2 / conv2_2 on the halo kernel with tap + max-pool in its epilogue, 256+ images also conv3_3 (256-channel tile).
-    All of them must produce the same bits (a streamed bank is featurised in passes of whatever size is left)."""
+    64+ images of 64 x 64 put conv1_2 / conv2_2 on the halo kernel with tap + max-pool in its epilogue, 256+ images also conv3_3 (256-channel
+    tile); at 256 x 256, 4 images are enough for conv1_2 and 16 for conv2_x.  All of them must produce the same bits (a streamed bank is
+    featurised in passes of whatever size is left)."""
     from ganleaks_amd.lpips import LpipsModel
     rng = np.random.default_rng(5)
-    imgs = rng.integers(0, 256, size=(288, 3, 64, 64), dtype=np.uint8)
+    imgs = rng.integers(0, 256, size=(n, 3, res, res), dtype=np.uint8)
     rows = {}
-    for per_pass in (16, 96, 288):
+    for per_pass in passes:
         m = LpipsModel().load_state_dicts(synth.vgg16_state_dict(7), lin)
         m.set_chunk(per_pass)
         fb = m.features(imgs, role=role)
         rows[per_pass] = (fb.V.numpy().copy(), fb.norms.numpy().copy())
-    for per_pass in (96, 288):
-        assert np.array_equal(rows[16][0].view(np.uint8), rows[per_pass][0].view(np.uint8)), "V differs between passes of 16 and %d images" % per_pass
-        assert np.array_equal(rows[16][1], rows[per_pass][1])
+    for per_pass in passes[1:]:
+        assert np.array_equal(rows[passes[0]][0].view(np.uint8), rows[per_pass][0].view(np.uint8)), \
+            "V differs between passes of %d and %d images" % (passes[0], per_pass)
+        assert np.array_equal(rows[passes[0]][1], rows[per_pass][1])
 
 
 def test_lattice_and_hilo_search_rows_agree(gl, synth, model, lin, oracle):
