@@ -52,6 +52,16 @@ struct GlGatherConv {
     //   V[img][tap_off + pin * cols + c] = v / (|v|_channels + eps) * tap_coef[c]   (pin = position inside the image; tap_fmt 1: fp16 row
     //   of tap_ldv bytes, 0: split row), tap_pool[img][y/2][x/2][c] = max of the 2 x 2 window in the split layout.  `out` is NOT written.
     // The sum of squares over the channels uses the epilogue's canonical order (gl_conv_h3_epi.h), which lpips_tap_*_split_kernel repeat.
+    // gather_conv_h3 only, with pixnorm_act > 0 and cols <= 128 (so that every tile shape a pass may get holds all channels): PGGAN's toRGB, the
+    // 1 x 1 convolution to <= 4 image channels that follows the last block (gan_models/pggan/model_torch.py:60-62,84-88), taken from the normalised
+    // activations while they are in registers: rgb_out[o * 4 + c] = rgb_b[c] + rgb_inv_act * sum_ch rgb_w[c * cols + ch] * v[ch]   (v = the values the
+    // split store would hold; the sum in the epilogue's canonical order: fp32 fma chain over the 4 channels of a lane, balanced tree over the
+    // 16-channel tiles, then (g0 + g1) + (g2 + g3) over the lane groups).  `out` is NOT written: the 2.1 GB of a 128-image pass at 256 x 256
+    // never reach HBM.
+    const float *rgb_w, *rgb_b;
+    float *rgb_out;             // nullptr = off
+    int rgb_n;
+    float rgb_inv_act;
     char *tap_V;                // nullptr = off
     const float *tap_coef;
     int64_t tap_ldv, tap_off;

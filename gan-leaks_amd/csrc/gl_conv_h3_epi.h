@@ -171,6 +171,78 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
         const float A = p.pixnorm_act;
 #pragma unroll
         for (int j = 0; j < TP; ++j) pinv[j] = __fdiv_rn(A, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss[j], (float)p.cols), __fmul_rn(__fmul_rn(1e-8f, A), A))));
+        if (p.rgb_out) {
+            // ---- toRGB on the normalised values (what the split store would hold: hi + lo), nothing else is stored
+            float res[TP][4];
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                float t[TC][4];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[i][c] = 0.0f;
+                    if (ch < p.cols) {
+                        float vv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = __fmul_rn(acc[i][j][r], pinv[j]);
+                            const float cl = fminf(fmaxf(v, -65504.0f), 65504.0f);
+                            saturated |= (cl != v) && (o4[j] >= 0);
+                            const _Float16 hi = (_Float16)cl;
+                            const _Float16 lo = (_Float16)fmaf(acc[i][j][r], pinv[j], -(float)hi);
+                            vv[r] = __fadd_rn((float)hi, (float)lo);
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (c < p.rgb_n) {
+                                const float4 w = *reinterpret_cast<const float4 *>(p.rgb_w + (int64_t)c * p.cols + ch);
+                                t[i][c] = fmaf(w.w, vv[3], fmaf(w.z, vv[2], fmaf(w.y, vv[1], fmaf(w.x, vv[0], 0.0f))));
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int w = 1; w < TC; w *= 2)
+#pragma unroll
+                        for (int k = 0; k < TC; k += 2 * w) t[k][c] = __fadd_rn(t[k][c], t[k + w][c]);
+                    res[j][c] = t[0][c];
+                }
+            }
+            if constexpr (WC > 1) {
+                // the other channel half of the position sits in the partner wave: the top level of the tree over the tiles
+                static_assert(WC == 2, "fused toRGB: one or two waves along the channels");
+                float *xr = reinterpret_cast<float *>(smem + 8192 + 16384);          // [WP][TP][4][64]
+                __syncthreads();
+                if (wc == 1) {
+#pragma unroll
+                    for (int j = 0; j < TP; ++j)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) xr[((wp_ * TP + j) * 4 + c) * 64 + lane] = res[j][c];
+                }
+                __syncthreads();
+                if (wc == 1) return saturated;
+#pragma unroll
+                for (int j = 0; j < TP; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) res[j][c] = __fadd_rn(res[j][c], xr[((wp_ * TP + j) * 4 + c) * 64 + lane]);
+            }
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                float out4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float sacc = res[j][c];
+                    sacc = __fadd_rn(sacc, __shfl_xor(sacc, 16, 64));
+                    sacc = __fadd_rn(sacc, __shfl_xor(sacc, 32, 64));
+                    out4[c] = c < p.rgb_n ? fmaf(sacc, p.rgb_inv_act, p.rgb_b[c]) : 0.0f;
+                }
+                if (fk == 0 && o4[j] >= 0) *reinterpret_cast<float4 *>(p.rgb_out + (int64_t)o4[j] * 4) = make_float4(out4[0], out4[1], out4[2], out4[3]);
+            }
+            return saturated;
+        }
     }
 #pragma unroll
     for (int i = 0; i < TC; ++i) {

@@ -227,10 +227,14 @@ int pg_make_h3(gl_pggan *g, void *h3_slot, const std::vector<float> &pk, size_t 
 
 // pixnorm: the layer is followed by PixelNorm.  In split-fp16 mode it is applied in the convolution's epilogue whenever one tile holds all
 // output channels (everything up to 256 channels); *pixnorm_done says whether it was.
+// rgb_tail >= 0: this is the last convolution before toRGB layer `rgb_tail`; when its PixelNorm rides in the epilogue and it has <= 128 channels
+// (every tile shape then holds all of them, whatever the pass size) toRGB is taken there too and written to rgb_out [pos][4]; *rgb_done says so.
 int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int Cin, const float *w, const float *bias, int cols, int ntaps, int act,
-            float *out, const gl_pggan::H3 *h3 = nullptr, bool rgb = false, bool *pixnorm_done = nullptr)
+            float *out, const gl_pggan::H3 *h3 = nullptr, bool rgb = false, bool *pixnorm_done = nullptr, int rgb_tail = -1, float *rgb_out = nullptr,
+            bool *rgb_done = nullptr)
 {
     if (pixnorm_done) *pixnorm_done = false;
+    if (rgb_done) *rgb_done = false;
     GlGatherConv p = {};
     p.in = in; p.positions = m * H * W; p.H = H; p.W = W; p.Cin = Cin; p.up = up;
     p.wpack = w; p.cols = cols; p.cols_pad = cols_pad_of(cols); p.ntaps = ntaps;
@@ -251,6 +255,11 @@ int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int C
         if (fuse && pixnorm_done && !rgb && p.cols <= gl_conv_h3_tile_channels(p, 1)) {
             p.pixnorm_act = kPgAct;
             *pixnorm_done = true;
+            static const int fuse_rgb = getenv("GL_RGB_FUSE") ? atoi(getenv("GL_RGB_FUSE")) : 1;
+            if (fuse_rgb && rgb_tail >= 0 && rgb_out && rgb_done && p.cols <= 128 && g->nc <= 4) {
+                p.rgb_w = g->w_rgb[rgb_tail]; p.rgb_b = g->b_rgb[rgb_tail]; p.rgb_out = rgb_out; p.rgb_n = g->nc; p.rgb_inv_act = 1.0f / kPgAct;
+                *rgb_done = true;
+            }
         }
         return gl_launch_gather_conv_h3(g->ctx, p, 1);
     }
@@ -490,20 +499,24 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
         if (!normed) rc = pg_pixelnorm(g, g->ws_buf[1], m * 16, C);
         if (rc != GL_OK) return rc;
         int cur = 1, prev = 1, hw = 4;
+        bool rgb_done = false;
         for (int s = 0; s < steps; ++s) {
             hw *= 2;
             const int b1 = (cur + 1) % 3, b2 = (cur + 2) % 3;
             rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 1, g->cin[s], g->w_blk[s][0], g->b_blk[s][0], g->cout[s], 9, 2, g->ws_buf[b1], &g->h_blk[s][0], false, &normed);
             if (rc == GL_OK && !normed) rc = pg_pixelnorm(g, g->ws_buf[b1], m * hw * hw, g->cout[s]);
-            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2], &g->h_blk[s][1], false, &normed);
+            if (rc == GL_OK) rc = pg_conv(g, g->ws_buf[b1], m, hw, hw, 0, g->cout[s], g->w_blk[s][1], g->b_blk[s][1], g->cout[s], 9, 2, g->ws_buf[b2], &g->h_blk[s][1], false, &normed,
+                                          s + 1 == steps ? steps : -1, g->ws_rgb[0], &rgb_done);
             if (rc == GL_OK && !normed) rc = pg_pixelnorm(g, g->ws_buf[b2], m * hw * hw, g->cout[s]);
             if (rc != GL_OK) return rc;
             prev = cur;      // input of this block (low resolution): `upscaled` of the reference is its x2 view
             cur = b2;
         }
-        // toRGB
-        rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 0, rgb_cin(g, steps), g->w_rgb[steps], g->b_rgb[steps], nc, 1, 0, g->ws_rgb[0], &g->h_rgb[steps], true);
-        if (rc != GL_OK) return rc;
+        // toRGB (unless the last convolution's epilogue has already written it)
+        if (!rgb_done) {
+            rc = pg_conv(g, g->ws_buf[cur], m, hw, hw, 0, rgb_cin(g, steps), g->w_rgb[steps], g->b_rgb[steps], nc, 1, 0, g->ws_rgb[0], &g->h_rgb[steps], true);
+            if (rc != GL_OK) return rc;
+        }
         const float *brgb = nullptr;
         if (steps > 0 && alpha != 1.0f) {
             // rgb[steps-1](upscaled): the 1x1 convolution commutes with nearest upsampling, so it runs at half resolution.

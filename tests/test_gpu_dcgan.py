@@ -194,6 +194,17 @@ def test_large_pass_tiles_match_small_pass_tiles(gl, synth):
     p.set_chunk(20)
     small = p.forward_device(zp, 3, 1.0, True, False)[0].numpy()
     assert big.shape == (260, 3, 32, 32) and np.array_equal(small, big)
+    # 128 x 128 with 64 channels in the last block: PixelNorm AND toRGB ride in the last convolution's epilogue -- of the halo kernel for the
+    # pass of 20 images, of the tap-gather kernel for passes of 2; fade-in (alpha < 1) adds the separate toRGB of the previous block
+    p = PGGAN(64, 256, 3)
+    p.load_state_dict(synth.pggan_state_dict(4, 64, 256))
+    zp = synth.latent(11, 20, 64)
+    for alpha in (1.0, 0.4):
+        p.set_chunk(20)
+        big = p.forward_device(zp, 5, alpha, True, False)[0].numpy()
+        p.set_chunk(2)
+        small = p.forward_device(zp, 5, alpha, True, False)[0].numpy()
+        assert big.shape == (20, 3, 128, 128) and np.array_equal(small, big)
 
 
 def test_fused_tail_matches_separate_launches(gl, synth, oracle):
