@@ -80,3 +80,57 @@ def test_config2_size_properties(gl):
     assert np.array_equal(i3, idx) and np.array_equal(d3, dist)
     print("\nconfig-2 size: attack() from host arrays %.3f s; gl_fbb_knn_l2_host (PCIe-inclusive) %.3f s = %.0f query-images/s"
           % (t_attack, t_host, Q / t_host))
+
+
+def test_config2_size_properties_l2_lpips(gl):
+    """The reference's default distance (0.2 * LPIPS + L2) at the same size, seeded VGG16 + the vendored lin weights: planted copies come back
+    with the smallest index holding those bytes and a distance that is zero up to the fp32 rounding of the norms (< 1e-5 at |V|^2 ~ 1); reported distances agree with the
+    small-problem path (which the fp64 oracle and the reference's goldens pin) on the reported neighbour and on a random sample of other rows,
+    none of which is closer; two shards min-merged, and the bank streamed in chunks, reproduce the resident result bit for bit."""
+    import os
+    from ganleaks_amd import synth
+    from ganleaks_amd.lpips import LpipsModel, feat_knn_keys
+    from ganleaks_amd.attack import unpack_keys
+    N, Q, B = 100_000, 10_000, 64
+    n_eff = (N // B) * B
+    rng = np.random.default_rng(77)
+    proto = rng.integers(0, 256, size=(2048, 3, 64, 64), dtype=np.uint8)
+    bank = proto[rng.integers(0, 2048, size=N)]
+    rows = rng.integers(0, N, size=N // 2)
+    bank[rows, :, :8, :8] = rng.integers(0, 256, size=(len(rows), 3, 8, 8), dtype=np.uint8)
+    q = bank[rng.integers(0, N, size=Q)].copy()
+    planted = rng.integers(0, n_eff, size=500)
+    q[:500] = bank[planted]
+    q[500:, :, 8:24, 8:24] = rng.integers(0, 256, size=(Q - 500, 3, 16, 16), dtype=np.uint8)
+    lin = np.load(os.path.join(os.path.dirname(__file__), "golden", "lpips_lin_v0.1.npz"))
+    model = LpipsModel().load_state_dicts(synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
+    ctx = gl.Context.get()
+
+    fq = model.features(q, role="query")
+    fb = model.features(bank[:n_eff], role="bank")
+    dist, idx = unpack_keys(ctx, feat_knn_keys(fb, fq), Q, fq.K, "f32")
+    assert idx.max() < n_eff and idx.min() >= 0
+    assert np.all(dist[:500] < 1e-5)          # |V|^2 ~ 1 for these noise images: the fp32 rounding of |q|^2 + |n|^2 - 2 q.n
+    flat = bank[:n_eff].reshape(n_eff, -1)
+    for k in range(0, 500, 25):
+        same = np.flatnonzero((flat == q[k].reshape(-1)).all(axis=1))
+        assert idx[k] == same[0]
+    # self-consistency through the small-problem path: the reported neighbour + 63 random rows, one query at a time
+    for k in rng.integers(0, Q, size=12):
+        others = rng.integers(0, n_eff, size=63)
+        cand = np.concatenate([[idx[k]], others])
+        d_small, i_small = gl.attack(q[k:k + 1], bank[cand], distance="l2-lpips", batch_size=64, lpips=model)
+        assert d_small[0] > dist[k] - 1e-5       # nothing in the sample is closer
+        d_self, _ = gl.attack(q[k:k + 1], np.repeat(bank[idx[k]][None], 64, axis=0), distance="l2-lpips", batch_size=64, lpips=model)
+        assert abs(float(d_self[0]) - float(dist[k])) < 1e-5
+    # two shards, min-merged keys == unsharded, for all Q results
+    half = (n_eff // 2 // B) * B
+    keys = None
+    for lo, hi in ((half, n_eff), (0, half)):
+        keys = feat_knn_keys(model.features(bank[lo:hi], index_base=lo, role="bank"), fq, keys=keys)
+    d2, i2 = unpack_keys(ctx, keys, Q, fq.K, "f32")
+    assert np.array_equal(i2, idx) and np.array_equal(d2, dist)
+    del fb
+    # the bank streamed through HBM in chunks of ~24 GiB of feature rows
+    d3, i3 = gl.attack(fq, bank, distance="l2-lpips", batch_size=B, lpips=model, chunk_bytes=24 << 30)
+    assert np.array_equal(i3, idx) and np.array_equal(d3, dist)
