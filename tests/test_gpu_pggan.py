@@ -139,3 +139,26 @@ def test_pggan256_bank_attack_against_c_oracle(gl, synth):
     d, i = gl.attack(q, bank, batch_size=32)
     od, oi, _ = c_oracle.knn_l2_u8(hb, q, 32)
     assert np.array_equal(i, oi) and np.array_equal(d, od) and i[0] == 7 and i[1] == 50 and i[2] != 69
+
+
+def test_configs3_shape_end_to_end_streamed(gl, synth, golden_dir):
+    """configs[3] in small: PGGAN steps=6 generated chunk by chunk (GeneratedBank), VGG16 + LPIPS at 256 x 256 on lattice search rows, the bank
+    streamed through HBM with the query rows resident; planted queries (copies of generated samples) come back with their index, and the
+    result equals the one on the materialised bank bit for bit."""
+    import os
+    from ganleaks_amd.attack import GeneratedBank
+    from ganleaks_amd.lpips import LpipsModel
+    from ganleaks_amd.gan_models.pggan.model_torch import Generator
+    gen = Generator(64, 256, 3)
+    gen.load_state_dict(synth.pggan_state_dict(4321 + 256, 64, 256))
+    lin = np.load(os.path.join(golden_dir, "lpips_lin_v0.1.npz"))
+    model = LpipsModel().load_state_dicts(synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
+    z = synth.latent(31, 96, 64)
+    whole = gen.generate_u8(z, steps=6, alpha=1.0).numpy()
+    planted = np.array([3, 40, 95, 64])
+    q = np.concatenate([whole[planted], synth.perturb_u8(3, whole[[10, 70]], 4.0)])
+    row = 2 * int(gl.Context.get().lib.gl_lpips_lattice_dim(256, 256))
+    d_res, i_res = gl.attack(q, whole, distance="l2-lpips", batch_size=32, lpips=model)
+    assert np.array_equal(i_res[:4], planted) and np.all(d_res[:4] < 1e-5) and i_res[4] == 10 and i_res[5] == 70
+    d, i = gl.attack(q, GeneratedBank(gen, z, steps=6, alpha=1.0), distance="l2-lpips", batch_size=32, lpips=model, chunk_bytes=20 * row)
+    assert np.array_equal(i, i_res) and np.array_equal(d, d_res)
