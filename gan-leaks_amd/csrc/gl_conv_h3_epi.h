@@ -171,7 +171,9 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
         const float A = p.pixnorm_act;
 #pragma unroll
         for (int j = 0; j < TP; ++j) pinv[j] = __fdiv_rn(A, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss[j], (float)p.cols), __fmul_rn(__fmul_rn(1e-8f, A), A))));
-        if (p.rgb_out) {
+        // (compiled only into the tiles that can hold such a layer: the 256-channel tile's main loop has no register to spare, and code it never
+        //  runs cost it an accumulator tile spilled and reloaded in every K slice -- DCGAN fell from 526 k to 475 k images / s)
+        if constexpr (16 * TC * WC <= 128) if (p.rgb_out) {
             // ---- toRGB on the normalised values (what the split store would hold: hi + lo), nothing else is stored
             float res[TP][4];
 #pragma unroll
