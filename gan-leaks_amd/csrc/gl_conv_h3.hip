@@ -41,8 +41,9 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 // layers (and, round 2, the 128 x 512 tile WITH the fused RGB tail for DCGAN's last hidden layer: 636 B of scratch, 186 -> 214 ms per step), a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU, staggered staging of the two wave halves,
 // halo staging (one staged pixel range per channel chunk, taps as shifted rows).  Also tried (round 2): GEMM rows in border-sorted order (the 9
 // classes first / inner / last row x column), so that tiles inside one class SKIP the K slices of their outside taps -- 23 % of the MFMAs of
-// DCGAN's 4 x 4 -> 8 x 8 layer, 12 % of the next one, bit-identical outputs -- measured 2 % on those layers: MFMAs on zero operands cost
-// little of the power budget that sets the clock, and the rows need per-piece addressing.  Not kept.
+// DCGAN's 4 x 4 -> 8 x 8 layer, 12 % of the next one, bit-identical outputs.  Measured with clean K loops (tools/check_loop_spills.py): the
+// headline step went from 192 to 210-222 ms.  A class-pure tile of 256 rows spans 64 to 256 images instead of 16, and the re-use of an input
+// pixel by its 4 taps x 4 phases, which a raster tile gets from its own L2 footprint, is gone.  Not kept.
 // UP: the input is read through nearest-neighbour x2 upsampling (p.up; a template parameter so that the common form does not carry its registers)
 template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
