@@ -38,7 +38,7 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 // of gl_pair256.h on this kernel (inline-asm fragment reads with counted waits, a ring of two weight tiles, the barrier before the last
 // weight tile, DMA pieces spread over the weight tiles: bit-identical, 2-3 % SLOWER on every generator -- round 2), a 128 x 256
 // tile with 8 waves of 64 x 64, 256 x 256 with 4 waves of 128 x 128 (1 wave per SIMD), 128 x 512 / 128 x 256 tiles for 128-column
-// layers (and, round 2, the 128 x 512 tile WITH the fused RGB tail for DCGAN's last hidden layer: 636 B of scratch, 186 -> 214 ms per step), a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU, staggered staging of the two wave halves,
+// layers (and, round 2, the 128 x 512 tile WITH the fused RGB tail for DCGAN's last hidden layer, K loop free of spills: 193 -> 211-220 ms per step; that layer's K is only 32 slices long, and one 8-wave workgroup per CU cannot hide its long epilogue behind another workgroup's main loop the way two 128 x 128 ones do), a ring of three slices with counted s_waitcnt vmcnt(N), 4 workgroups per CU, staggered staging of the two wave halves,
 // halo staging (one staged pixel range per channel chunk, taps as shifted rows).  Also tried (round 2): GEMM rows in border-sorted order (the 9
 // classes first / inner / last row x column), so that tiles inside one class SKIP the K slices of their outside taps -- 23 % of the MFMAs of
 // DCGAN's 4 x 4 -> 8 x 8 layer, 12 % of the next one, bit-identical outputs.  Measured with clean K loops (tools/check_loop_spills.py): the
