@@ -14,9 +14,10 @@
 //   fragment read are 16 consecutive q (one image row segment), so every ds_read_b128 is conflict-free for ANY tap shift.
 //   Pixels outside the image are hardware zero fills (buffer loads beyond the descriptor's range).
 //
-// Tried for the WIDE layers too (round 2: 256-channel tile, 8 waves of 128 channels x 4 rows, column tiles): the halo offsets and the wider
-// fragment sets do not fit the 256 registers of a 2-waves-per-SIMD kernel -- ~9 scratch accesses per tap slice -- and PGGAN-256 fell from 376
-// to 300 TFLOP/s; the wide layers stay on the tap-gather kernel.
+// Tried for the WIDE layers too (round 2: 256-channel tile, 8 waves of 128 channels x 4 rows, column tiles).  First form: the halo offsets and the
+// wider fragment sets did not fit the 256 registers of a 2-waves-per-SIMD kernel (spills in the K loop, PGGAN-256 376 -> 300 TFLOP/s).  Lean form
+// (offsets recomputed per chunk, taps as a real loop; K loop free of spills, bit-identical): PGGAN-256 393.4 -> 393.2 / 396.9 TFLOP/s, configs[2]
+// 1603.5 -> 1601.7 ms -- nothing.  The wide layers are not bound by the staging the halo form saves; they stay on the tap-gather kernel.
 //
 // K order and MFMA order are those of gather_conv_h3_kernel (chunk-major, tap inside; lo*hi, hi*lo, hi*hi), so every output element
 // is the same fp32 sum: the two kernels are interchangeable bit for bit (a pass of another size may be dispatched to the other one).
