@@ -63,7 +63,7 @@ constexpr float kVScale = 16384.0f;     // V is stored as halves of V * 2^14 (va
 
 // "Lattice" search rows (8-bit images only): a pixel 2 c / 255 - 1 is m / 255 with m = 2 c - 255 an odd integer of 9 bits, so with the row
 // scale u = 255 sqrt(D) 2^e the image part of V * u is m * 2^e -- EXACT in one fp16, no hi / lo pair, one K segment of D halves instead of
-// three.  e is chosen so that u lies in (2^13, 2^14] like kVScale (u = 14 133.7 for every square power-of-two image size); the LPIPS part
+// three.  e is chosen so that u lies in (2^13, 2^14] like kVScale (u = 14 133.5 for every square power-of-two image size); the LPIPS part
 // is V * u rounded to fp16 as before.  The L2 term of the distance is then exact up to the fp32 accumulation, and the contraction is
 // K_lp + D long (the algorithmic length) instead of K_lp + 3 D.
 static inline int lp_lattice_exp(int64_t D) { return (int)std::floor(std::log2(16384.0 / (255.0 * std::sqrt((double)D)))); }
