@@ -96,7 +96,8 @@ int gl_launch_gather_conv(gl_ctx *ctx, const GlGatherConv &p, int phases);
 
 // split-fp16 variant (gl_conv_h3.hip): `in` and `wpack` are in the split layout (see that file); same parameter block
 int gl_launch_gather_conv_h3(gl_ctx *ctx, const GlGatherConv &p, int phases);
-// output channels one workgroup tile of gl_launch_gather_conv_h3 will cover for this problem (the fused PixelNorm needs cols <= that)
+// output channels one workgroup tile of gl_launch_gather_conv_h3 will cover for this problem as far as the fused epilogues (PixelNorm, tap,
+// toRGB) are concerned: they need cols <= that; 0 for the tiles that have none
 int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases);
 // whether gl_launch_gather_conv_h3 can take the tap_* fields for this problem (all channels in one tile, the 2 x 2 window inside one wave)
 bool gl_conv_h3_tap_fusable(const GlGatherConv &p, int phases);

@@ -342,7 +342,8 @@ int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases)
 {
     if (gl_conv_halo_applies(p, phases)) return p.cols <= 64 ? 64 : 128;
     const int t = h3_tile_choice(p, phases);
-    return t == 2 ? 256 : (t == 1 || t == 4) ? 64 : 128;       // tiles 0, 3 and 5 hold 128 channels
+    // the 8 x 4 wave tiles (2: 256 x 256, 5: 128 x 512) have no fused epilogue (gl_conv_h3_epi.h): 0
+    return (t == 2 || t == 5) ? 0 : (t == 1 || t == 4) ? 64 : 128;       // tiles 0 and 3 hold 128 channels
 }
 
 bool gl_conv_h3_tap_fusable(const GlGatherConv &p, int phases)

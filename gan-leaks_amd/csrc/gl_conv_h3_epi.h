@@ -27,12 +27,17 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
     // lane's 4 channels as an fmaf chain, then (g0 + g1) + (g2 + g3) over the 4 lane groups; then a balanced binary tree over the tiles --
     // which pixelnorm_split_kernel (gl_pggan.hip) reproduces on stored values: fused or not, and whatever the tile shape, the stored
     // activations are bit-identical (a pass of another size may pick another tile).  Pass 2 below stores v * inv.
-    const bool pixnorm = p.pixnorm_act > 0.0f;
-    const bool tap = p.tap_V != nullptr;
+    // The fused epilogues (PixelNorm, LPIPS tap + pool, toRGB) exist only in the tiles whose waves hold 4 x 4 accumulator tiles.  In the 8 x 4 forms
+    // (<2,4,8,4>, <1,8,8,4>) they spill hundreds of registers: measured, PixelNorm fused into the 256-channel tile made PGGAN-256 2 % SLOWER than
+    // the separate pass, the relu3_3 tap fused there made VGG16 2 % slower -- and code the K loop never runs can still cost it an accumulator
+    // (tools/check_loop_spills.py).  The launcher never asks those tiles for a fused epilogue (gl_conv_h3_tile_channels returns 0 for them).
+    constexpr bool kFusable = TC <= 4;
+    const bool pixnorm = kFusable && p.pixnorm_act > 0.0f;
+    const bool tap = kFusable && p.tap_V != nullptr;
     float pinv[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) pinv[j] = 1.0f;
-    if (pixnorm || tap) {
+    if constexpr (kFusable) if (pixnorm || tap) {
         float tss[TC][TP];
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
@@ -171,9 +176,7 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
         const float A = p.pixnorm_act;
 #pragma unroll
         for (int j = 0; j < TP; ++j) pinv[j] = __fdiv_rn(A, __fsqrt_rn(__fadd_rn(__fdiv_rn(ss[j], (float)p.cols), __fmul_rn(__fmul_rn(1e-8f, A), A))));
-        // (compiled only into the tiles that can hold such a layer: the 256-channel tile's main loop has no register to spare, and code it never
-        //  runs cost it an accumulator tile spilled and reloaded in every K slice -- DCGAN fell from 526 k to 475 k images / s)
-        if constexpr (16 * TC * WC <= 128) if (p.rgb_out) {
+        if (p.rgb_out) {
             // ---- toRGB on the normalised values (what the split store would hold: hi + lo), nothing else is stored
             float res[TP][4];
 #pragma unroll
