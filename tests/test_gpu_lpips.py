@@ -331,8 +331,8 @@ def test_host_one_call_falls_back_when_split_fp16_saturates(gl, synth, lin):
 @pytest.mark.parametrize("role,res,n,passes", [("bank", 64, 288, (16, 96, 288)), (None, 64, 288, (16, 96, 288)), ("bank", 256, 20, (4, 20))])
 def test_feature_rows_do_not_depend_on_the_pass_size(role, res, n, passes, gl, synth, lin):
     """The images-per-pass setting picks the kernels: small passes run every tap as its own kernel behind the tap-gather convolution,
-    64+ images of 64 x 64 put conv1_2 / conv2_2 on the halo kernel with tap + max-pool in its epilogue, 256+ images also conv3_3 (256-channel
-    tile); at 256 x 256, 4 images are enough for conv1_2 and 16 for conv2_x.  All of them must produce the same bits (a streamed bank is
+    64+ images of 64 x 64 put conv1_2 / conv2_2 on the halo kernel with tap + max-pool in its epilogue (conv3_3, on the 256-channel tile, keeps
+    its stand-alone tap); at 256 x 256, 4 images are enough for conv1_2 and 16 for conv2_x.  All of them must produce the same bits (a streamed bank is
     featurised in passes of whatever size is left)."""
     from ganleaks_amd.lpips import LpipsModel
     rng = np.random.default_rng(5)
