@@ -129,6 +129,7 @@ SIGNATURES = {
     "gl_comm_init_rank": (_i, [_p, _p, _i, _i, _pp]),
     "gl_comm_init_all": (_i, [_pp, _i, _pp]),
     "gl_comm_destroy": (_i, [_p]),
+    "gl_comm_abort": (_i, [_p]),
     "gl_comm_rank": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "gl_allreduce_min_keys": (_i, [_p, _p, _i64]),
     "gl_comm_group_start": (_i, []),
@@ -332,6 +333,12 @@ class Comm:
         if getattr(self, "handle", None) is not None:
             self.ctx.lib.gl_comm_destroy(self.handle)
             self.handle = None
+
+    def abort(self):
+        """ncclCommAbort: end the communicator without waiting for its queued collectives (error path; callable from any thread)"""
+        h, self.handle = getattr(self, "handle", None), None
+        if h is not None:
+            self.ctx.lib.gl_comm_abort(h)
 
     def __del__(self):
         try:

@@ -242,12 +242,12 @@ def _feature_row_bytes(ctx, model, images):
     return 4 * int(ctx.lib.gl_lpips_feature_dim(h, w))
 
 
-def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath=None):
+def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath=None, index_base=0):
     """bank rows [0, n_rows) pass through HBM in chunks of at most `chunk_bytes` of prepared rows (int8 rows for 'l2', feature
     rows for 'l2-lpips'); the packed keys accumulate the minimum across chunks (atomicMin), so the result is the one the
-    resident form gives.  `bank` is a GeneratedBank or a host array / DeviceArray of images."""
+    resident form gives.  `bank` is a GeneratedBank or a host array / DeviceArray of images (`index_base`: global index of its row 0)."""
     generated = getattr(bank, "kind", None) == "generated"
-    base = bank.index_base if generated else 0
+    base = bank.index_base if generated else int(index_base)
 
     def rows(lo, hi):
         if generated:
@@ -270,7 +270,7 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
             per_q = _feature_row_bytes(ctx, model, queries)
             q_step = max(1, int(_query_budget_bytes(chunk_bytes) // per_q))
             if len(queries) > q_step:
-                parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath)
+                parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath, index_base)
                          for a in range(0, len(queries), q_step)]
                 return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
         raw_queries = getattr(queries, "kind", None) != "feat"
@@ -321,7 +321,22 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
     raise AssertionError("unreachable")
 
 
-def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None, chunk_bytes=None, float_path=None):
+def prepare_queries(queries, distance, ctx=None, lpips=None):
+    """the query side of attack() prepared once, for callers that search several banks (a sweep, the chunks of a sharded bank) or want
+    the fallible part (uploads, VGG16 features) done before a collective: int8 rows for 'l2', LPIPS search rows for 'l2-lpips' when
+    they fit the streaming budget -- otherwise the images are returned as they are and attack() slices them itself."""
+    if isinstance(queries, Bank) or getattr(queries, "kind", None) == "feat" or not len(queries):
+        return queries
+    if distance == "l2-lpips":
+        from . import lpips as _lp
+        model = lpips or _lp.default_model()
+        if len(queries) * _feature_row_bytes(model.ctx, model, queries) > _budget_bytes():
+            return queries
+        return model.features(queries, role=model.search_role("query"))
+    return Bank.from_images(queries, ctx or Context.get(), keep_u8=True)
+
+
+def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None, lpips=None, chunk_bytes=None, float_path=None, index_base=0):
     """nearest bank sample of every query.
 
     queries : [Q,C,H,W] images, u8 or float; numpy / torch / DeviceArray / Bank / FeatureBank
@@ -336,6 +351,8 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
     returns (dist float32 [Q], idx int64 [Q]); idx < (N // batch_size) * batch_size (fbb.py:77),
     smallest index on ties (fbb.py:86).
     reduce_fn: optional callable(keys DeviceArray) -> keys DeviceArray, the cross-GPU min (shard.py).
+    index_base: for an unprepared image array that is one shard of a larger bank: the global index of its row 0 (prepared and generated
+              banks carry their own).  Like them, a shard (index_base > 0 or reduce_fn given) is not truncated again.
     float_path: 'exact' | 'mfma' for rows that are on neither lattice (see attack.float_path; default $GANLEAKS_FLOAT_PATH or 'exact').
     """
     if distance not in ("l2", "l2-lpips"):
@@ -350,7 +367,8 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
     else:
         ctx = ctx or Context.get()
         n_total = len(bank)
-        n_rows = (n_total // int(batch_size)) * int(batch_size)
+        index_base = int(index_base)
+        n_rows = n_total if (reduce_fn is not None or index_base) else (n_total // int(batch_size)) * int(batch_size)
     if n_rows == 0 and reduce_fn is None:
         # the reference dies in torch.cat([]) (fbb.py:83) with ValueError
         raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
@@ -360,7 +378,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
         model = lpips or _lp.default_model()
     if not prepared:
         chunk_bytes = _budget_bytes() if chunk_bytes is None else int(chunk_bytes)
-        if generated:
+        if generated or n_rows == 0:         # (an empty shard still takes part in the reduction: the streamed form handles it)
             need = chunk_bytes + 1
         else:
             per_img = int(np.prod(tuple(bank.shape[1:]), dtype=np.int64)) if len(bank) else 0
@@ -373,7 +391,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
             else:
                 need = 2 * per_img * n_rows          # u8 codes + int8 rows
         if need > chunk_bytes:
-            return _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, float_path)
+            return _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, float_path, index_base)
     if not prepared and n_rows > 0:
         if isinstance(bank, DeviceArray):
             bank = bank.view((n_rows,) + tuple(bank.shape[1:]))
@@ -382,7 +400,8 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
 
     if distance == "l2-lpips":
         q_feat = getattr(queries, "kind", None) == "feat"
-        fb = bank if prepared else model.features(bank, role=model.search_role("bank"), fmt=getattr(queries, "fmt", None) if q_feat else None)
+        fb = bank if prepared else model.features(bank, index_base=index_base, role=model.search_role("bank"),
+                                                  fmt=getattr(queries, "fmt", None) if q_feat else None)
         q_role = "query" if getattr(fb, "role", None) else None          # queries follow the bank's row format
         if q_feat:
             fq = queries
@@ -393,7 +412,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
                 # off-lattice float queries against lattice rows of an 8-bit bank: both sides in the hi / lo layout instead
                 if prepared or getattr(fb, "fmt", None) != "lattice":
                     raise
-                fb = model.features(bank, role="bank", fmt="hilo")
+                fb = model.features(bank, index_base=index_base, role="bank", fmt="hilo")
                 fq = model.features(queries, role="query", fmt="hilo")
         keys = _lp.feat_knn_keys(fb, fq, n_rows)
         if reduce_fn is not None:
@@ -401,7 +420,7 @@ def attack(queries, bank, distance="l2", batch_size=64, ctx=None, reduce_fn=None
         return unpack_keys(ctx, keys, fq.n, fb.K, "f32")
 
     if not prepared:
-        bank = Bank.from_images(bank, ctx, keep_u8=True)
+        bank = Bank.from_images(bank, ctx, index_base=index_base, keep_u8=True)
     keys, q, kind = knn_keys(bank, queries, n_rows, fpath=float_path)
     if reduce_fn is not None:
         keys = reduce_fn(keys)

@@ -5,8 +5,11 @@ query set is searched in one launch of the HIP pairwise kernel instead of Q x (N
 Python iterations (attack_models/fbb.py:156-159, 73-88).
 
 Additions (flagged [build] in SURVEY.md 5): --distance {l2,l2-lpips} (the reference hard-wires
-'l2-lpips', fbb.py:148).  The reference has no `attack()`; the batched entry point named by the
-project brief lives in ganleaks_amd.attack.attack and is re-exported here.
+'l2-lpips', fbb.py:148); --ngpu N / --devices 0,1,... shard the PNG bank over GPUs (the reference is
+single-device, fbb.py:40): rank r uploads and searches rows [bounds[r], bounds[r+1]) of the sorted file list,
+one all-reduce(min) of the packed keys gives the single-device result bit for bit (ganleaks_amd.shard).
+The reference has no `attack()`; the batched entry point named by the project brief lives in
+ganleaks_amd.attack.attack and is re-exported here.
 """
 from __future__ import annotations
 
@@ -17,7 +20,7 @@ import warnings
 
 import numpy as np
 
-from ..attack import Bank, _budget_bytes, attack  # noqa: F401  (re-export)
+from ..attack import Bank, _budget_bytes, attack, prepare_queries  # noqa: F401  (re-export)
 from .utils import (Loss, check_folder, get_filepaths_from_dir, read_images_u8_nchw, save_files)
 
 
@@ -37,6 +40,8 @@ _FLAGS = (
     (('--wandb',), dict(default=None, help='accepted for compatibility; nothing is logged to WandB')),
     (('--distance',), dict(type=str, default='l2-lpips', choices=['l2', 'l2-lpips'],
                            help="[build] distance operator; the reference always uses 'l2-lpips' (fbb.py:148)")),
+    (('--ngpu',), dict(type=int, default=1, help='[build] shard the bank over the first N GPUs (one context and host thread per GPU, RCCL min)')),
+    (('--devices',), dict(type=str, default=None, help='[build] explicit device ordinals for the shards, e.g. 0,1,2,3 (overrides --ngpu)')),
 )
 
 
@@ -154,8 +159,34 @@ def plot_closest_images(idx, query_imgs_u8, syn_imgs_u8, save_dir, class_type, n
         PIL.Image.fromarray(np.uint8(f * 255)).save(os.path.join(save_dir, str(i) + class_type + '.png'))
 
 
+def shard_devices(args):
+    """device ordinals the bank is sharded over, or None for the single-device path (--devices wins over --ngpu)"""
+    devices = getattr(args, "devices", None)
+    if devices:
+        if isinstance(devices, str):
+            devices = [int(d) for d in devices.replace(",", " ").split()]
+        return [int(d) for d in devices]
+    ngpu = int(getattr(args, "ngpu", 1) or 1)
+    if ngpu < 1:
+        raise ValueError("--ngpu must be at least 1")
+    return list(range(ngpu)) if ngpu > 1 else None
+
+
 def main(args):
     """attack_models/fbb.py:111-179."""
+    devices = shard_devices(args)
+    group = None
+    if devices is not None:
+        from ..shard import DeviceGroup
+        group = DeviceGroup(devices)                 # one context per GPU for the whole sweep: models and query rows are kept
+    try:
+        return _main(args, group)
+    finally:
+        if group is not None:
+            group.close()
+
+
+def _main(args, group):
     if args.hyperparameter_search:
         subdirs = [os.path.join(args.syn_data_path, o) for o in os.listdir(args.syn_data_path)
                    if os.path.isdir(os.path.join(args.syn_data_path, o))]
@@ -174,21 +205,22 @@ def main(args):
         resolution = args.resolution
 
         syn_imgs = read_images_u8_nchw(get_filepaths_from_dir(subdir, ext='png'), resolution)
-        if queries is None or queries[0] != (args.pos_data_dir, args.neg_data_dir, resolution, distance):
+        if group is not None:
+            # [build] the bank sharded over GPUs: every context prepares the (replicated) queries itself, so nothing is prepared here
+            if queries is None or queries[0] != (args.pos_data_dir, args.neg_data_dir, resolution, distance):
+                pos_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.pos_data_dir, ext='png'), resolution)
+                neg_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.neg_data_dir, ext='png'), resolution)
+                queries = ((args.pos_data_dir, args.neg_data_dir, resolution, distance), pos_query_imgs, neg_query_imgs, None,
+                           np.concatenate([pos_query_imgs, neg_query_imgs]))
+        elif queries is None or queries[0] != (args.pos_data_dir, args.neg_data_dir, resolution, distance):
             # the query sets do not change across the banks of a hyper-parameter sweep (fbb.py:114-123 re-reads them for every
             # sub-directory): read and prepare them once -- int8 rows, or VGG16/LPIPS search rows -- and reuse them for every bank
             pos_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.pos_data_dir, ext='png'), resolution)
             neg_query_imgs = read_images_u8_nchw(get_filepaths_from_dir(args.neg_data_dir, ext='png'), resolution)
             custom_loss = Loss(distance, if_norm_reg=False)      # fbb.py:148 (loads the LPIPS model for 'l2-lpips')
             both = np.concatenate([pos_query_imgs, neg_query_imgs])
-            if distance == "l2-lpips":
-                model = custom_loss.lpips_model
-                row = 2 * int(model.ctx.lib.gl_lpips_search_dim(resolution, resolution)) if model.search_rows == "fp16" else 4 * int(
-                    model.ctx.lib.gl_lpips_feature_dim(resolution, resolution))
-                # only when the rows fit the streaming budget; otherwise attack() slices the raw queries itself
-                prepared = model.features(both, role=model.search_role("query")) if len(both) * row <= _budget_bytes() else both
-            else:
-                prepared = Bank.from_images(both, keep_u8=True) if len(both) else both
+            # prepared only when the rows fit the streaming budget; otherwise attack() slices the raw queries itself
+            prepared = prepare_queries(both, distance, lpips=custom_loss.lpips_model)
             queries = ((args.pos_data_dir, args.neg_data_dir, resolution, distance), pos_query_imgs, neg_query_imgs, custom_loss, prepared)
         _, pos_query_imgs, neg_query_imgs, custom_loss, prepared = queries
         n_rows = (len(syn_imgs) // args.BATCH_SIZE) * args.BATCH_SIZE
@@ -198,7 +230,10 @@ def main(args):
         # prepared rows -- int8 rows or VGG16/LPIPS feature rows -- are built once, and streamed through HBM in chunks when
         # they would not fit (ganleaks_amd.attack, $GANLEAKS_CHUNK_GB)
         n_pos = len(pos_query_imgs)
-        all_d, all_i = attack(prepared, syn_imgs, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
+        if group is not None:
+            all_d, all_i = group.attack(prepared, bank=syn_imgs, distance=distance, batch_size=args.BATCH_SIZE)
+        else:
+            all_d, all_i = attack(prepared, syn_imgs, distance=distance, batch_size=args.BATCH_SIZE, lpips=custom_loss.lpips_model)
         pos_d, pos_i, neg_d, neg_i = all_d[:n_pos], all_i[:n_pos], all_d[n_pos:], all_i[n_pos:]
         pos_loss = pos_d.astype(np.float64).reshape(-1, 1)          # python floats -> float64 [Q,1] (fbb.py:160)
         plt_pos_idx = pos_i.reshape(-1, 1)

@@ -25,6 +25,7 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -55,6 +56,7 @@ RcclApi *rccl()
         api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
         api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
@@ -145,6 +147,21 @@ int gl_comm_destroy(gl_comm *c)
     (void)hipStreamSynchronize(c->ctx->stream);
     if (api->handle && c->comm) (void)api->CommDestroy(c->comm);
     delete c;
+    return GL_OK;
+}
+
+int gl_comm_abort(gl_comm *c)
+{
+    // no stream synchronisation here: the point is to end a reduce that can never complete (a peer rank failed before queueing its half)
+    if (!c) return GL_OK;
+    RcclApi *api = rccl();
+    ncclResult_t r = ncclSuccess;
+    if (api->handle && c->comm) r = api->CommAbort(c->comm);
+    delete c;
+    if (r != ncclSuccess) {
+        gl_set_error("ncclCommAbort failed: %s", api->GetErrorString(r));
+        return GL_ERR_RCCL;
+    }
     return GL_OK;
 }
 

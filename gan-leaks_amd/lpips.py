@@ -187,11 +187,27 @@ class LpipsModel:
         return FeatureBank(ctx, V, norms, n, K, K - 3 * H * W, index_base)
 
 
-_default = {"model": None}
+_default = {"model": None, "factory": None}
 
 
 def set_default_model(model):
     _default["model"] = model
+
+
+def set_default_factory(factory):
+    """factory(ctx) -> LpipsModel with its weights loaded, for callers that need one model per context (shard.DeviceGroup: a context per
+    GPU); None restores the default, LpipsModel.from_files(ctx=ctx) on the local weight files."""
+    _default["factory"] = factory
+
+
+def model_for(ctx):
+    """the LPIPS model of a given context: the registered factory's, else the default model when it lives on that context, else a new
+    one from the local weight files"""
+    if _default["factory"] is not None:
+        return _default["factory"](ctx)
+    if _default["model"] is not None and _default["model"].ctx is ctx:
+        return _default["model"]
+    return LpipsModel.from_files(ctx=ctx)
 
 
 def default_model():

@@ -72,15 +72,42 @@ def make_comm(ctx, group=None):
     """the native RCCL communicator of a `torch.distributed`-launched job (one process per GPU): rank 0 draws the unique id, the process
     group that the launcher set up carries its 128 bytes to the other ranks (the only thing torch is used for), every rank joins with its
     Context.  Returns None for a world of one.  The data-path collective is then `comm.allreduce_min_keys(keys)` -- queued on the
-    context's stream by libganleaks_hip.so itself (gl_allreduce_min_keys), no torch tensor involved."""
+    context's stream by libganleaks_hip.so itself (gl_allreduce_min_keys), no torch tensor involved.
+
+    Every rank leaves this function the same way: if rank 0 cannot draw the id (librccl missing, ncclGetUniqueId failing) it broadcasts
+    the error text instead and ALL ranks raise GanLeaksError(GL_ERR_RCCL); if some rank cannot join, an all-reduce of a success flag
+    makes the others drop their communicator and raise too -- so a caller that falls back to another route (bench.py --collective)
+    does so on every rank, with the process group's collectives still matched."""
+    import torch
     import torch.distributed as dist
-    from ._lib import Comm
+    from ._lib import Comm, GanLeaksError, GL_ERR_RCCL
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [Comm.unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [("id", Comm.unique_id())]
+        except Exception as e:  # noqa: BLE001  (whatever it is, the other ranks must hear of it)
+            box = [("err", "rank 0: %s" % (e,))]
     dist.broadcast_object_list(box, src=0, group=group)
-    return Comm(ctx, box[0], rank, world)
+    tag, payload = box[0]
+    if tag != "id":
+        raise GanLeaksError(GL_ERR_RCCL, "no RCCL unique id: %s" % payload)
+    comm, why = None, ""
+    try:
+        comm = Comm(ctx, payload, rank, world)
+    except Exception as e:  # noqa: BLE001
+        why = str(e)
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        ok = ok.to("cuda:%d" % ctx.device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) != 1:
+        if comm is not None:
+            comm.abort()
+        raise GanLeaksError(GL_ERR_RCCL, "the RCCL communicator could not be formed on every rank%s" % (": " + why if why else ""))
+    return comm
 
 
 def allreduce_min_keys(keys, group=None, comm=None, _even_alone=False):
@@ -117,70 +144,163 @@ def allreduce_min_keys_host(keys_host, group=None):
     return t.numpy().view(np.uint64)
 
 
-def attack_on_devices(queries, make_generator, z, devices=None, distance="l2", batch_size=64, make_lpips=None, weights=None, **generate_kwargs):
-    """The sharded attack inside ONE process: a host thread per GPU, each with its own context, generates and searches its range of the
-    latents; the packed keys are min-reduced by RCCL between the contexts (`gl_comm_init_all` + `gl_allreduce_min_keys`, each on its own
-    stream).  When RCCL cannot form the communicator -- it refuses two ranks on one device, which is how the single-GPU tests drive
-    this -- the keys are merged on the host instead (Q x 8 bytes per device).  The alternative to one process per GPU for callers
-    without a launcher.
+class DeviceGroup:
+    """The sharded attack inside ONE process: a context per GPU, a host thread per context and call, the packed keys min-reduced by RCCL
+    between the contexts (`gl_comm_init_all` + `gl_allreduce_min_keys`, each on its own stream).  When RCCL cannot form the
+    communicator -- it refuses two ranks on one device, which is how the single-GPU tests drive this -- the keys are merged on the host
+    instead (Q x 8 bytes per device).  The alternative to one process per GPU for callers without a launcher.
 
-    make_generator(ctx) -> a generator bound to that context with its weights loaded (e.g. dcgan.Generator(100, 3, 64, ctx) + load_state_dict)
-    make_lpips(ctx)     -> an LpipsModel for 'l2-lpips'
+    The group outlives a call: the LPIPS model of every context and the prepared (replicated) query rows are kept, so a sweep over many
+    banks with the same queries (attack_models/fbb.py:114-123) featurises them once per device.
+
+    Failure handling: everything that can fail without the other ranks (building the generator and the LPIPS model, uploading and
+    featurising the queries) runs BEFORE a host rendezvous; if any rank failed there, no rank queues a collective.  A failure after it
+    (e.g. out of memory on a bank chunk) aborts every communicator (gl_comm_abort = ncclCommAbort), which ends the reduce kernels the
+    other ranks may already have queued, so the call raises instead of hanging the GPUs; the group is unusable afterwards."""
+
+    def __init__(self, devices=None):
+        from ._lib import Comm, Context, GanLeaksError, GL_ERR_RCCL, device_count
+        devices = list(range(device_count())) if devices is None else [int(d) for d in devices]
+        if not devices:
+            raise ValueError("no devices")
+        self.devices, self.world = devices, len(devices)
+        self.contexts = [Context(d) for d in devices]
+        self.comms = None
+        if self.world > 1:
+            try:
+                self.comms = Comm.init_all(self.contexts)
+            except GanLeaksError as e:
+                if e.code != GL_ERR_RCCL:
+                    raise
+        self._models = [None] * self.world
+        self._queries = [None] * self.world          # (key, prepared rows) per rank
+        self._broken = False
+
+    @property
+    def collective(self):
+        return "rccl" if self.comms is not None else ("host-merge" if self.world > 1 else "none")
+
+    def attack(self, queries, make_generator=None, z=None, bank=None, distance="l2", batch_size=64, make_lpips=None, weights=None,
+               **generate_kwargs):
+        """see attack_on_devices"""
+        import threading
+        from ._lib import DeviceArray
+        from .attack import GeneratedBank, attack, prepare_queries
+        if self._broken:
+            raise RuntimeError("this DeviceGroup failed in an earlier call; build a new one")
+        if (bank is None) == (make_generator is None):
+            raise ValueError("needs either make_generator + z or bank=")
+        if getattr(queries, "kind", None) in ("feat", "u8", "int", "f32"):
+            raise TypeError("queries must be host images: prepared rows live on one context, every context of the group prepares its own")
+        if bank is None and z is None:
+            raise ValueError("make_generator needs the latents z")
+        world, contexts, comms = self.world, self.contexts, self.comms
+        if isinstance(bank, DeviceArray):
+            bank = bank.numpy()
+        n_total = len(bank) if bank is not None else len(z)
+        n_eff = (n_total // int(batch_size)) * int(batch_size)
+        if n_eff == 0:
+            raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
+        bounds = weighted_bounds(n_eff, weights, int(batch_size)) if weights is not None else [n_eff * r // world for r in range(world + 1)]
+        host = HostMerge(world)
+        ready = threading.Barrier(world)
+        results, errors, lock = [None] * world, [], threading.Lock()
+        qkey = (id(queries), distance, tuple(getattr(queries, "shape", ())))
+
+        def reduce_fn_for(rank, ctx):
+            if comms is not None:
+                return comms[rank].allreduce_min_keys
+            if world == 1:
+                return None
+            return lambda keys: ctx.to_device(host.merge(rank, keys.numpy()))
+
+        def fail(e, after_setup):
+            with lock:
+                errors.append(e)
+                ready.abort()
+                host.abort()
+                if after_setup:
+                    self._broken = True
+                    for c in comms or []:
+                        c.abort()                             # idempotent; ends reduces that can no longer complete
+
+        def work(rank):
+            shard = None
+            try:
+                ctx = contexts[rank]
+                lo, hi = bounds[rank], bounds[rank + 1]
+                if bank is None:
+                    shard = GeneratedBank(make_generator(ctx), z[lo:hi], index_base=lo, **generate_kwargs)
+                else:
+                    shard = bank[lo:hi]
+                model = None
+                if distance == "l2-lpips":
+                    if self._models[rank] is None:
+                        if make_lpips is not None:
+                            self._models[rank] = make_lpips(ctx)
+                        else:
+                            from .lpips import model_for
+                            self._models[rank] = model_for(ctx)
+                    model = self._models[rank]
+                if self._queries[rank] is None or self._queries[rank][0] != qkey:
+                    self._queries[rank] = (qkey, prepare_queries(queries, distance, ctx, model), queries)   # (keeps `queries` alive: id() stays unique)
+                prepared = self._queries[rank][1]
+                ctx.sync()
+            except BaseException as e:  # noqa: BLE001
+                fail(e, False)
+                return
+            try:
+                ready.wait()                                  # every rank is set up: from here on collectives may be queued
+            except threading.BrokenBarrierError:
+                return                                        # another rank failed in its setup; nothing was queued
+            try:
+                results[rank] = attack(prepared, shard, distance=distance, batch_size=batch_size, ctx=ctx, reduce_fn=reduce_fn_for(rank, ctx),
+                                       lpips=model, index_base=lo)
+            except BaseException as e:  # noqa: BLE001
+                fail(e, True)
+
+        threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            first = [e for e in errors if not isinstance(e, threading.BrokenBarrierError)]
+            raise (first or errors)[0]
+        return results[0]
+
+    def close(self):
+        """communicators, cached models and query rows, then the contexts (a failed group leaves its contexts to the process: the
+        tracebacks keep the workers' objects alive)"""
+        for c in self.comms or []:
+            c.destroy()
+        self.comms = None
+        self._models = [None] * self.world
+        self._queries = [None] * self.world
+        if not self._broken:
+            import gc
+            gc.collect()
+            for c in self.contexts:
+                c.destroy()
+        self.contexts = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+def attack_on_devices(queries, make_generator=None, z=None, devices=None, distance="l2", batch_size=64, make_lpips=None, weights=None,
+                      bank=None, **generate_kwargs):
+    """One sharded attack on a DeviceGroup built for the call.  The bank is either generated on the devices or handed over:
+      make_generator(ctx), z -> rank r generates rows [bounds[r], bounds[r+1]) from z[lo:hi] with a generator bound to its context
+                                (e.g. dcgan.Generator(100, 3, 64, ctx) + load_state_dict); never materialised;
+      bank                   -> a host array [N,C,H,W] (u8 codes or floats; numpy / CPU torch; a DeviceArray is read back once): what the
+                                reference's fbb.main reads from image_*.png (attack_models/fbb.py:133-135).  Rank r uploads its rows only.
+    make_lpips(ctx)     -> an LpipsModel for 'l2-lpips' (default: lpips.model_for(ctx): the registered factory, else the local weight files)
     devices             -> list of device ordinals (default: all visible); weights -> relative speeds for `weighted_bounds`
     returns (dist float32 [Q], idx int64 [Q]), identical to the single-device result."""
-    import threading
-    from ._lib import Comm, Context, GanLeaksError, GL_ERR_RCCL, device_count
-    from .attack import GeneratedBank, attack
-    devices = list(range(device_count())) if devices is None else list(devices)
-    if not devices:
-        raise ValueError("no devices")
-    world = len(devices)
-    n_eff = (len(z) // int(batch_size)) * int(batch_size)
-    if n_eff == 0:
-        raise ValueError("bank holds no full batch of %d samples (attack_models/fbb.py:77-83)" % int(batch_size))
-    bounds = weighted_bounds(n_eff, weights, int(batch_size)) if weights is not None else [n_eff * r // world for r in range(world + 1)]
-    contexts = [Context(d) for d in devices]
-    comms = None
-    if world > 1:
-        try:
-            comms = Comm.init_all(contexts)
-        except GanLeaksError as e:
-            if e.code != GL_ERR_RCCL:
-                raise
-    host = HostMerge(world)
-    results, errors = [None] * world, []
-
-    def reduce_fn_for(rank, ctx):
-        if comms is not None:
-            return comms[rank].allreduce_min_keys
-        if world == 1:
-            return None
-        return lambda keys: ctx.to_device(host.merge(rank, keys.numpy()))
-
-    def work(rank):
-        gen = bank = model = None
-        try:
-            ctx = contexts[rank]
-            gen = make_generator(ctx)
-            lo, hi = bounds[rank], bounds[rank + 1]
-            bank = GeneratedBank(gen, z[lo:hi], index_base=lo, **generate_kwargs)
-            model = make_lpips(ctx) if (distance == "l2-lpips" and make_lpips is not None) else None
-            results[rank] = attack(queries, bank, distance=distance, batch_size=batch_size, ctx=ctx, reduce_fn=reduce_fn_for(rank, ctx), lpips=model)
-        except BaseException as e:  # noqa: BLE001
-            errors.append(e)
-            host.abort()
-
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join()
-    for c in comms or []:
-        c.destroy()
-    if errors:
-        raise errors[0]             # (the traceback keeps the worker's objects alive: their contexts are left to the process)
-    import gc
-    gc.collect()                    # generators, banks and models of the workers are gone: their contexts can go too
-    for c in contexts:
-        c.destroy()
-    return results[0]
+    with DeviceGroup(devices) as group:
+        return group.attack(queries, make_generator, z, bank, distance, batch_size, make_lpips, weights, **generate_kwargs)

@@ -161,6 +161,10 @@ int gl_comm_unique_id(void *id_out_host);                                       
 int gl_comm_init_rank(gl_ctx *ctx, const void *id_host, int rank, int nranks, gl_comm **out);  /* ncclCommInitRank on ctx's device */
 int gl_comm_init_all(gl_ctx *const *ctxs, int n, gl_comm **out_comms);                         /* ncclCommInitAll; out_comms[n] */
 int gl_comm_destroy(gl_comm *comm);
+/* ncclCommAbort: ends the communicator and whatever collective of it is still queued or running on ANY of its ranks' streams, without waiting.
+ * For the error path of a multi-rank job: a rank that fails before its gl_allreduce_min_keys leaves the other ranks' reduce kernels waiting on the
+ * GPU for ever; aborting every local communicator (from any host thread) lets their streams drain.  The handle is freed, as by gl_comm_destroy. */
+int gl_comm_abort(gl_comm *comm);
 int gl_comm_rank(const gl_comm *comm, int *out_rank, int *out_nranks);
 /* keys_dev[q] = min over ranks of keys_dev[q], in place: ncclAllReduce(ncclMin, ncclUint64) queued on the context's stream -- behind the search
  * kernel that wrote the keys, ahead of gl_keys_unpack*; no host synchronisation.  Q x 8 bytes (80 KB at Q = 10^4): latency-bound. */

@@ -1,0 +1,141 @@
+"""GPU: the sharded attack on a MATERIALISED bank -- what the reference's entry point reads from image_*.png
+(attack_models/fbb.py:133-135) -- through shard.DeviceGroup / attack_on_devices(bank=...) and `fbb.py --ngpu / --devices`,
+driven the way ONE GPU allows: several contexts on device 0 (RCCL refuses that, the host merge takes over).  The failure paths
+(a rank failing during its setup, a rank failing after the rendezvous) must raise, not hang."""
+import os
+
+import numpy as np
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _lpips_factory(synth, golden_dir):
+    from ganleaks_amd.lpips import LpipsModel
+    lin = np.load(os.path.join(golden_dir, "lpips_lin_v0.1.npz"))
+    lind = {"lin%d" % k: lin["lin%d" % k] for k in range(5)}
+    vgg = synth.vgg16_state_dict(7)
+    return lambda ctx: LpipsModel(ctx).load_state_dicts(vgg, lind)
+
+
+def test_materialised_bank_sharded_equals_single_device(synth, golden_dir):
+    import c_oracle
+    import ganleaks_amd as gl
+    from ganleaks_amd import shard
+    case = synth.attack_case(411, 1000, 40, 40, 32)            # 1000 rows: n_eff = 960, shards of 320 (not multiples of 64 apart from 0)
+    q = np.concatenate([case["pos"], case["neg"]])
+    od, oi, _ = c_oracle.knn_l2_u8(case["bank"], q, 64)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        d, i = shard.attack_on_devices(q, bank=case["bank"], devices=devices, batch_size=64)
+        assert np.array_equal(i, oi) and np.array_equal(d, od), devices
+    assert oi.max() < 960
+    # float images on the lattice and a DeviceArray bank are accepted too; weights change the cut, never the result
+    f = (2.0 * (case["bank"] / 255.0) - 1.0).astype(np.float32)
+    d, i = shard.attack_on_devices(q, bank=gl.Context.get().to_device(f), devices=[0, 0], batch_size=64, weights=[1.0, 2.5])
+    assert np.array_equal(i, oi) and np.array_equal(d, od)
+    # more ranks than full batches: empty shards take part in the reduction
+    d, i = shard.attack_on_devices(q, bank=case["bank"][:130], devices=[0, 0, 0], batch_size=64)
+    od2, oi2, _ = c_oracle.knn_l2_u8(case["bank"][:130], q, 64)
+    assert np.array_equal(i, oi2) and np.array_equal(d, od2)
+    # l2-lpips: search rows per shard, indices global; a group kept across banks featurises the queries once per context
+    make_lpips = _lpips_factory(synth, golden_dir)
+    model = make_lpips(gl.Context.get())
+    bank64 = synth.lowpass_u8_images(21, 200, 64)
+    q64 = np.concatenate([synth.perturb_u8(22, bank64[[3, 77, 191]], 3.0), synth.lowpass_u8_images(23, 4, 64)])
+    d0, i0 = gl.attack(q64, bank64, distance="l2-lpips", batch_size=64, lpips=model)
+    with shard.DeviceGroup([0, 0]) as group:
+        assert group.collective == "host-merge"
+        d1, i1 = group.attack(q64, bank=bank64, distance="l2-lpips", batch_size=64, make_lpips=make_lpips)
+        rows = [qq[1] for qq in group._queries]
+        d2, i2 = group.attack(q64, bank=bank64[::-1].copy(), distance="l2-lpips", batch_size=64, make_lpips=make_lpips)
+        assert all(a[1] is b for a, b in zip(group._queries, rows))            # the query rows of the first call were reused
+    assert np.array_equal(i1, i0) and np.array_equal(d1, d0) and list(i0[:3]) == [3, 77, 191]
+    d3, i3 = gl.attack(q64, bank64[::-1].copy(), distance="l2-lpips", batch_size=64, lpips=model)
+    assert np.array_equal(i2, i3) and np.array_equal(d2, d3)
+
+
+def test_a_failing_rank_raises_instead_of_hanging(synth):
+    import ganleaks_amd as gl
+    from ganleaks_amd import shard
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    sd = synth.dcgan_state_dict(1234)
+    z = synth.latent(5, 256)
+    q = synth.lowpass_u8_images(9, 6, 64)
+    calls = []
+
+    def make_generator(ctx):
+        calls.append(ctx)
+        if len(calls) == 2:
+            raise RuntimeError("rank setup failed on purpose")
+        g = Generator(100, 3, 64, ctx)
+        g.load_state_dict(sd)
+        return g
+
+    with pytest.raises(RuntimeError, match="on purpose"):          # during setup: nobody has queued a collective
+        shard.attack_on_devices(q, make_generator, z, devices=[0, 0, 0], batch_size=64)
+
+    class Flaky:
+        """a generator whose second chunk fails: the rank dies after the rendezvous, while the others wait in the merge"""
+        def __init__(self, ctx, fail):
+            self.ctx, self.fail = ctx, fail
+            self.g = Generator(100, 3, 64, ctx)
+            self.g.load_state_dict(sd)
+
+        def generate_u8(self, zz, **kw):
+            if self.fail:
+                raise MemoryError("bank chunk failed on purpose")
+            return self.g.generate_u8(zz, **kw)
+
+    made = []
+
+    def make_flaky(ctx):
+        made.append(ctx)
+        return Flaky(ctx, len(made) == 1)
+
+    with pytest.raises(MemoryError, match="on purpose"):
+        shard.attack_on_devices(q, make_flaky, z, devices=[0, 0], batch_size=64)
+    # the process is still healthy
+    d, i = shard.attack_on_devices(q, lambda ctx: Flaky(ctx, False), z, devices=[0, 0], batch_size=64)
+    assert len(d) == 6 and i.max() < 256
+    with pytest.raises(ValueError):
+        shard.attack_on_devices(q, devices=[0])                      # neither a generator nor a bank
+    with pytest.raises(ValueError):
+        shard.attack_on_devices(q, make_flaky, z, devices=[0], bank=np.zeros((64, 3, 64, 64), np.uint8))
+
+
+def test_fbb_ngpu_flag_matches_single_device(tmp_path, monkeypatch, synth, golden_dir):
+    import PIL.Image
+    from ganleaks_amd import lpips
+    from ganleaks_amd.attack_models import fbb
+    bank = synth.lowpass_u8_images(31, 140, 32)
+    pos = synth.perturb_u8(32, bank[[1, 50, 127, 139]], 3.0)
+    neg = synth.lowpass_u8_images(33, 5, 32)
+    for name, imgs in (("syn", bank), ("pos", pos), ("neg", neg)):
+        os.makedirs(tmp_path / name)
+        for k, im in enumerate(imgs):
+            PIL.Image.fromarray(im.transpose(1, 2, 0)).save(tmp_path / name / ("image_%d.png" % k))
+    monkeypatch.chdir(tmp_path)
+    base = ["--syn_data_path", str(tmp_path / "syn"), "--pos_data_dir", str(tmp_path / "pos"), "--neg_data_dir", str(tmp_path / "neg"),
+            "--resolution", "32", "--BATCH_SIZE", "64"]
+    factory = _lpips_factory(synth, golden_dir)
+    import ganleaks_amd as gl
+    lpips.set_default_model(factory(gl.Context.get()))
+    lpips.set_default_factory(factory)
+    try:
+        for distance in ("l2", "l2-lpips"):
+            fbb.main(fbb.parse_arguments(base + ["--exp_name", "one_" + distance, "--distance", distance]))
+            a = fbb.parse_arguments(base + ["--exp_name", "two_" + distance, "--distance", distance, "--devices", "0,0,0"])
+            assert fbb.shard_devices(a) == [0, 0, 0]
+            fbb.main(a)
+            for f in ("pos_loss", "neg_loss", "pos_nn_idx", "neg_nn_idx", "pos_idx"):
+                one = np.load(tmp_path / "fbb_attack" / ("one_" + distance) / (f + ".npy"))
+                two = np.load(tmp_path / "fbb_attack" / ("two_" + distance) / (f + ".npy"))
+                assert np.array_equal(one, two), (distance, f)
+            assert (tmp_path / "fbb_attack" / ("two_" + distance) / "0pos.png").exists()
+    finally:
+        lpips.set_default_model(None)
+        lpips.set_default_factory(None)
+    assert fbb.shard_devices(fbb.parse_arguments(base + ["--ngpu", "4"])) == [0, 1, 2, 3]
+    assert fbb.shard_devices(fbb.parse_arguments(base)) is None

@@ -121,3 +121,60 @@ def test_host_merge_survives_repeated_calls_with_skewed_threads():
         want = data[r].min(axis=0)
         for rank in range(world):
             assert np.array_equal(out[rank][r], want), (r, rank)
+
+
+def _make_comm_worker(rank, world, port, scenario, out_dir):
+    """make_comm must leave every rank the same way: rank 0 failing to draw the id, or one rank failing to join, raises
+    GanLeaksError on ALL ranks, and the process group's next collective still matches."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import ganleaks_amd  # noqa: F401
+    from ganleaks_amd import _lib, shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    aborted = []
+
+    class FakeComm:
+        def __init__(self, ctx, uid, r, n):
+            if scenario == "join" and r == 1:
+                raise _lib.GanLeaksError(_lib.GL_ERR_RCCL, "ncclCommInitRank failed on purpose")
+            assert uid == b"u" * 128
+
+        def abort(self):
+            aborted.append(rank)
+
+        @staticmethod
+        def unique_id():
+            if scenario == "id":
+                raise _lib.GanLeaksError(_lib.GL_ERR_RCCL, "RCCL is not available: on purpose")
+            return b"u" * 128
+
+    _lib.Comm = FakeComm
+    outcome = "ok"
+    try:
+        c = shard.make_comm(None)
+        assert isinstance(c, FakeComm)
+    except _lib.GanLeaksError as e:
+        assert e.code == _lib.GL_ERR_RCCL
+        outcome = "rccl-error"
+    # what bench.py does next: a vote over the launcher's group -- must not hang or mismatch
+    t = torch.tensor([1 if outcome == "ok" else 0], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    with open(os.path.join(out_dir, "%s_%d.txt" % (scenario, rank)), "w") as f:
+        f.write("%s %d %d" % (outcome, int(t.item()), len(aborted)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["id", "join", "fine"])
+def test_make_comm_fails_on_every_rank_or_none(scenario, tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_make_comm_worker, args=(world, _free_port(), scenario, str(tmp_path)), nprocs=world, join=True)
+    got = [open(tmp_path / ("%s_%d.txt" % (scenario, r))).read().split() for r in range(world)]
+    if scenario == "fine":
+        assert got == [["ok", "1", "0"]] * 2
+    else:
+        assert [g[:2] for g in got] == [["rccl-error", "0"]] * 2
+        if scenario == "join":
+            assert got[0][2] == "1" and got[1][2] == "0"        # the rank that had joined dropped its communicator
