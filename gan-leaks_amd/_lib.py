@@ -14,7 +14,10 @@ import threading
 import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libganleaks_hip.so")
+# $GANLEAKS_LIB: another build of the same ABI -- in practice libganleaks_hip_tuning.so (`make -C gan-leaks_amd/csrc tuning`), the only build
+# that reads the GL_* tuning variables and holds the experiment kernels; the A/B tools under tools/ set it, nothing else should
+LIB_PATH = os.environ.get("GANLEAKS_LIB") or os.path.join(_PKG_DIR, "libganleaks_hip.so")
+TUNING_LIB_PATH = os.path.join(_PKG_DIR, "libganleaks_hip_tuning.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "ganleaks.h")
 
 GL_OK = 0

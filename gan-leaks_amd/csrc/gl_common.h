@@ -66,6 +66,21 @@ void gl_set_error(const char *fmt, ...);
 
 static inline int64_t gl_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Tuning switches.  The shipped library has ONE code path per shape: gl_tuning_int() is the constant `dflt` there and the experiment
+// kernels (e.g. the DIAG instantiations of gl_pair256.h, whose results are wrong on purpose) are not compiled in.  `make tuning` builds
+// libganleaks_hip_tuning.so with -DGL_TUNING, where the named environment variable is read on every call (tools/bench_pairwise.py and the
+// other A/B tools alternate variants inside one process and load that library through $GANLEAKS_LIB).
+#ifdef GL_TUNING
+#include <cstdlib>
+static inline int gl_tuning_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+#else
+static constexpr int gl_tuning_int(const char *, int dflt) { return dflt; }
+#endif
+
 // every entry point runs on its context's device, whatever device the calling thread had current (a host thread may drive several contexts,
 // and PyTorch may have switched devices in between)
 static inline void gl_make_current(const gl_ctx *ctx)

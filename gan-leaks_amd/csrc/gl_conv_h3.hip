@@ -333,7 +333,7 @@ static int h3_tile_choice(const GlGatherConv &p, int phases)
     if (p.cols % 256 == 0 && gl_ceil_div(p.positions, 256) * (p.cols / 256) * phases >= 256) return 2;
     // 65..128 columns with many positions (PGGAN's 128-channel block at 128 x 128): 128 channels x 512 positions, 8 waves of 128 x 64 like the
     // wide tile's, all 160 KiB of LDS
-    static const int wide128 = getenv("GL_H3_TILE128") ? atoi(getenv("GL_H3_TILE128")) : 1;
+    const int wide128 = gl_tuning_int("GL_H3_TILE128", 1);
     if (wide128 && p.cols <= 128 && gl_ceil_div(p.positions, 512) * phases >= 512) return 5;
     return 0;
 }
@@ -348,7 +348,7 @@ int gl_conv_h3_tile_channels(const GlGatherConv &p, int phases)
 
 bool gl_conv_h3_tap_fusable(const GlGatherConv &p, int phases)
 {
-    static const int enabled = getenv("GL_TAP_FUSE") ? atoi(getenv("GL_TAP_FUSE")) : 1;
+    const int enabled = gl_tuning_int("GL_TAP_FUSE", 1);
     if (!enabled || phases != 1 || p.tail_w || p.out_mode != 2 || p.omul != 1 || p.Ho != p.H || p.Wo != p.W || p.planar) return false;
     if (p.cols > gl_conv_h3_tile_channels(p, phases) || p.H % 2 != 0 || p.W % 16 != 0) return false;
     if (gl_conv_halo_applies(p, phases)) return true;           // a wave owns 4 rows of its 16 x 16 block

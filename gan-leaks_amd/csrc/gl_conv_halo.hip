@@ -194,7 +194,7 @@ int launch_halo(gl_ctx *ctx, const GlGatherConv &p)
 
 bool gl_conv_halo_applies(const GlGatherConv &p, int phases)
 {
-    static const int enabled = getenv("GL_H3_HALO") ? atoi(getenv("GL_H3_HALO")) : 1;
+    const int enabled = gl_tuning_int("GL_H3_HALO", 1);
     if (!enabled || phases != 1 || p.ntaps != 9 || p.tail_w || p.cols > 128 || p.Cin % 32 != 0) return false;
     uint32_t dy = 0, dx = 0;
     for (int t = 0; t < 9; ++t) { dy |= (uint32_t)(t / 3) << (2 * t); dx |= (uint32_t)(t % 3) << (2 * t); }

@@ -166,6 +166,7 @@ l2_knn_i8_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ ba
 // in 128 KiB of LDS (one workgroup per CU); strips of 4 bank tiles so the 32 workgroups of an XCD cover 4 x 8 tiles.
 constexpr int BT = 256, BOPER = BT * TILE_K;
 
+#ifdef GL_TUNING      // the round-1 form of the 256 x 256 tile (plain double buffering): A/B material and the bit-for-bit check of the pipelined kernel
 __global__ void __launch_bounds__(512, 2)
 l2_knn_i8_256_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                      const int8_t *__restrict__ query, const int32_t *__restrict__ query_norm, int64_t nq, int64_t stride,
@@ -265,6 +266,7 @@ l2_knn_i8_256_kernel(const int8_t *__restrict__ bank, const int32_t *__restrict_
         if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
     }
 }
+#endif  // GL_TUNING
 
 // The same tile on the shared software-pipelined main loop (gl_pair256.h): fragment reads of the next MFMA block are issued before
 // the current block, one barrier per slice.
@@ -353,13 +355,16 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_L2_KNN);
     // the large tile needs enough tiles to fill 256 CUs; GL_L2_TILE=128|256 forces one (tuning / tests)
-    static const int force_tile = getenv("GL_L2_TILE") ? atoi(getenv("GL_L2_TILE")) : 0;
+    const int force_tile = gl_tuning_int("GL_L2_TILE", 0);
     const int64_t q256 = gl_ceil_div(nq, BT), n256 = gl_ceil_div(n_rows, BT);
     if (d <= 66051 && force_tile != 128 && (force_tile == 256 || q256 * n256 >= 1024)) {
+#ifdef GL_TUNING
         GL_ONCE_PER_DEVICE(ctx, \
             GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BOPER)););
-        const char *variant_env = getenv("GL_PAIR_VARIANT");          // read per call: tools/bench_pairwise.py alternates variants in one process
-    const int variant = variant_env ? atoi(variant_env) : 1;
+#endif
+#ifdef GL_TUNING
+        // tuning build only: 0 = the round-1 kernel, 2 / 4 = other DMA spreads, 11..14 = timing experiments whose RESULTS ARE WRONG (gl_pair256.h DIAG)
+        const int variant = gl_tuning_int("GL_PAIR_VARIANT", 1);
         GL_ONCE_PER_DEVICE(ctx, \
             GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
             GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)); \
@@ -371,6 +376,11 @@ int gl_l2_knn_i8(gl_ctx *ctx, const int8_t *bank_i8_dev, const int32_t *bank_nor
         auto k256 = variant == 0 ? l2_knn_i8_256_kernel : variant == 11 ? l2_knn_i8_256p_kernel<1, 8> : variant == 12 ? l2_knn_i8_256p_kernel<2, 8>
                     : variant == 13 ? l2_knn_i8_256p_kernel<3, 8> : variant == 14 ? l2_knn_i8_256p_kernel<4, 8> : variant == 4 ? l2_knn_i8_256p_kernel<0, 4> : variant == 2 ? l2_knn_i8_256p_kernel<0, 1>
                     : l2_knn_i8_256p_kernel<0, 8>;
+#else
+        GL_ONCE_PER_DEVICE(ctx, \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(l2_knn_i8_256p_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, gl_pair256::LDS_BYTES)););
+        auto k256 = l2_knn_i8_256p_kernel<0, 8>;
+#endif
         hipLaunchKernelGGL(k256, dim3((unsigned)(q256 * n256)), dim3(512), 4 * BOPER, ctx->stream, bank_i8_dev, bank_norm_dev, n_rows, index_base,
                            query_i8_dev, query_norm_dev, nq, stride, reinterpret_cast<unsigned long long *>(keys_dev), (int)q256, (int)n256, shift);
         GL_LAUNCH_CHECK();

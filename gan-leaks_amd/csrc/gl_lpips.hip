@@ -813,6 +813,7 @@ feat_knn_kernel(const char *__restrict__ bank, const float *__restrict__ bank_no
 // ---------------------------------------------------------------------------------------------
 constexpr int GT = 256, GOPER = GT * FROW;
 
+#ifdef GL_TUNING      // the round-1 kernel and the one-workgroup-per-tile pipelined kernel: A/B material of tools/bench_pairwise.py only
 __global__ void __launch_bounds__(512, 2)
 feat_knn_h1_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                    const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
@@ -973,6 +974,8 @@ feat_knn_h1p_kernel(const char *__restrict__ bank, const float *__restrict__ ban
     }
 }
 
+#endif  // GL_TUNING
+
 // ---------------------------------------------------------------------------------------------
 // feat_knn_h1c_kernel: the same search as ONE persistent launch of `clusters x members` workgroups (8 x 32 on an MI355X: one
 // workgroup per CU).  Why: K is 536 576 halves at 64 x 64 (8 384 slices, ~9 ms per tile) and 8.6 M at 256 x 256; with one
@@ -1082,6 +1085,88 @@ feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ ban
             best = o < best ? o : best;
             if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
         }
+    }
+}
+
+
+// The same arithmetic for a device that cannot hold a cluster's 4 x 8 super-tile (fewer than 256 compute units: a partitioned MI355X):
+// a persistent launch of one workgroup per CU that walks the tiles in strip order without meeting anyone.  Same main loop, same K
+// segments, same order of the segment totals, so a distance is the same bits on every device and in both kernels.
+__global__ void __launch_bounds__(512, 2)
+feat_knn_h1s_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
+                    const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, float inv_s2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    v4f *totals = reinterpret_cast<v4f *>(scratch + 4096 + (size_t)blockIdx.x * kTotalsPerWg);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wq = wave & 3;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int64_t nk = K1 / 64;
+    const int nseg = (int)((nk + kSegSlices - 1) / kSegSlices);
+    v4f *my_tot = totals + (size_t)wave * 32 * 64 + lane;
+    const unsigned tiles = (unsigned)q_tiles * (unsigned)n_tiles;
+    for (unsigned t = blockIdx.x; t < tiles; t += gridDim.x) {
+        int qt, nt;
+        {
+            constexpr int STRIP = 4;
+            const unsigned per_strip = (unsigned)STRIP * (unsigned)q_tiles;
+            const int strip = (int)(t / per_strip);
+            const unsigned r = t % per_strip;
+            const int width = n_tiles - strip * STRIP < STRIP ? n_tiles - strip * STRIP : STRIP;
+            nt = strip * STRIP + (int)(r % (unsigned)width);
+            qt = (int)(r / (unsigned)width);
+        }
+        const int64_t n0 = (int64_t)nt * GT, q0 = (int64_t)qt * GT;
+        const gl_pair256::Source sa = gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
+        const gl_pair256::Source sb = gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
+        v4f acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int seg = 0; seg < nseg; ++seg) {
+            const int64_t k0 = (int64_t)seg * kSegSlices;
+            const int64_t len = nk - k0 < kSegSlices ? nk - k0 : kSegSlices;
+            gl_pair256::mainloop<v8h>(sa, sb, len, smem, acc, wave, lane,
+                                      [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }, k0 * 128);
+            __syncthreads();
+            if (nseg > 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v4f *tt = my_tot + (i * 4 + j) * 64;
+                        if (seg > 0) acc[i][j] += *tt;
+                        if (seg + 1 < nseg) { *tt = acc[i][j]; acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
+        }
+        const int64_t nbase = n0 + wn * 128 + fk * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = q0 + wq * 64 + j * 16 + frow;
+            const float qn = q < nq ? query_norm[q] : 0.0f;
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t n = nbase + i * 16 + r;
+                    const float bn = n < n_rows ? bank_norm[n] : 0.0f;
+                    const float d = fmaxf(fmaf(-2.0f * inv_s2, acc[i][j][r], __fadd_rn(qn, bn)), 0.0f);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(index_base + n);
+                    if (n < n_rows && key < best) best = key;
+                }
+            unsigned long long o = __shfl_xor(best, 16, 64);
+            best = o < best ? o : best;
+            o = __shfl_xor(best, 32, 64);
+            best = o < best ? o : best;
+            if (fk == 0 && q < nq && best != ~0ull) atomicMin(&keys[q], best);
+        }
+        __syncthreads();           // the next tile's prologue refills the slice buffers
     }
 }
 
@@ -1513,18 +1598,15 @@ int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *ba
     const int64_t q_tiles = gl_ceil_div(nq, GT), n_tiles = gl_ceil_div(n_rows, GT);
     GL_REQUIRE(q_tiles * n_tiles < (1ll << 31), "gl_feat_knn_h1: grid too large");
     const int lds = 4 * GOPER;
-    GL_ONCE_PER_DEVICE(ctx, \
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
-    const char *variant_env = getenv("GL_PAIR_VARIANT");          // read per call: tools/bench_pairwise.py alternates variants in one process
-    const int variant = variant_env ? atoi(variant_env) : 3;
-    // the persistent cluster form (any problem size; needs 32 workgroup slots per cluster, i.e. a whole MI355X)
+    // variant 3: the persistent cluster form (needs 32 workgroup slots per cluster, i.e. a whole MI355X); 5: the persistent form without clusters
+    // (what a device with fewer compute units gets -- the same bits).  Tuning builds add 0 / 1 / 2 / 4: the one-workgroup-per-tile kernels.
+    const int variant = gl_tuning_int("GL_PAIR_VARIANT", 3);
     const int members = ctx->num_cu / kClusters;
-    if (variant == 3 && members >= kSuperN * kSuperQ) {
-        const size_t need = 4096 + (size_t)kClusters * members * kTotalsPerWg;
+    const bool clustered = variant == 3 && members >= kSuperN * kSuperQ;
+    if (clustered || variant == 3 || variant == 5) {
+        const int grid = clustered ? kClusters * members : (ctx->num_cu > 0 ? ctx->num_cu : 256);
+        const size_t need = 4096 + (size_t)grid * kTotalsPerWg;
         if (ctx->pair_scratch_bytes < need) {
             GL_HIP(hipStreamSynchronize(ctx->stream));
             (void)hipFree(ctx->pair_scratch);
@@ -1533,20 +1615,37 @@ int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *ba
             ctx->pair_scratch_bytes = need;
         }
         GL_ONCE_PER_DEVICE(ctx, \
-            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
-        GL_HIP(hipMemsetAsync(ctx->pair_scratch, 0, 4096, ctx->stream));         // the cluster counters
-        hipLaunchKernelGGL(feat_knn_h1c_kernel, dim3((unsigned)(kClusters * members)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
-                           bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
-                           reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members, inv_s2);
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1s_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
+        if (clustered) {
+            GL_HIP(hipMemsetAsync(ctx->pair_scratch, 0, 4096, ctx->stream));         // the cluster counters
+            hipLaunchKernelGGL(feat_knn_h1c_kernel, dim3((unsigned)grid), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
+                               bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
+                               reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members, inv_s2);
+        } else {
+            hipLaunchKernelGGL(feat_knn_h1s_kernel, dim3((unsigned)grid), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
+                               bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
+                               reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, inv_s2);
+        }
         GL_LAUNCH_CHECK();
         return GL_OK;
     }
+#ifdef GL_TUNING
+    GL_ONCE_PER_DEVICE(ctx, \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(feat_knn_h1p_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     auto kern = variant == 0 ? feat_knn_h1_kernel : variant == 4 ? feat_knn_h1p_kernel<4> : variant == 2 ? feat_knn_h1p_kernel<1> : feat_knn_h1p_kernel<8>;
     hipLaunchKernelGGL(kern, dim3((unsigned)(q_tiles * n_tiles)), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev), bank_norm_dev, n_rows,
                        index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1, reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles,
                        (int)n_tiles, inv_s2);
     GL_LAUNCH_CHECK();
     return GL_OK;
+#else
+    gl_set_error("gl_feat_knn_h1: unreachable dispatch");
+    return GL_ERR_STATE;
+#endif
 }
 
 int gl_feat_knn_h1(gl_ctx *ctx, const void *bank_V16_dev, const float *bank_norm_dev, int64_t n_rows, int64_t index_base, const void *query_V16_dev,

@@ -251,11 +251,11 @@ int pg_conv(gl_pggan *g, const float *in, int64_t m, int H, int W, int up, int C
         if (rgb) { p.cols = 4; p.cmod = 4; p.out_mode = 0; }      // 3 real + 1 padding column, fp32 [pos][4]
         else p.out_mode = 2;
         p.cols_pad = (int)gl_ceil_div(p.cols, 128) * 128;
-        static const int fuse = getenv("GL_PIXNORM_FUSE") ? atoi(getenv("GL_PIXNORM_FUSE")) : 1;      // 0: always the separate kernel (debugging)
+        const int fuse = gl_tuning_int("GL_PIXNORM_FUSE", 1);      // 0: always the separate kernel (debugging)
         if (fuse && pixnorm_done && !rgb && p.cols <= gl_conv_h3_tile_channels(p, 1)) {
             p.pixnorm_act = kPgAct;
             *pixnorm_done = true;
-            static const int fuse_rgb = getenv("GL_RGB_FUSE") ? atoi(getenv("GL_RGB_FUSE")) : 1;
+            const int fuse_rgb = gl_tuning_int("GL_RGB_FUSE", 1);
             if (fuse_rgb && rgb_tail >= 0 && rgb_out && rgb_done && p.cols <= 128 && g->nc <= 4) {
                 p.rgb_w = g->w_rgb[rgb_tail]; p.rgb_b = g->b_rgb[rgb_tail]; p.rgb_out = rgb_out; p.rgb_n = g->nc; p.rgb_inv_act = 1.0f / kPgAct;
                 *rgb_done = true;

@@ -88,3 +88,44 @@ def make_l2_lpips_loss(vgg_sd, lin):
     def loss(x_hat, x_gt):                     # utils.py:171-177; PerceptualLoss.forward(pred=x_hat, target=x_gt) -> forward_pair(target, pred)
         return 0.2 * lpips(x_gt, x_hat).view(-1) + torch.mean((x_gt - x_hat) ** 2, dim=[1, 2, 3])
     return loss
+
+
+def make_features_once(vgg_sd, lin):
+    """The "features-once" CPU variant BASELINE.md section 3 asks for beside the reference-literal loop: the SAME distance
+    0.2 * LPIPS + L2 (utils.py:176) evaluated the way the device path does -- VGG16 once per image, every tap normalised
+    (util/util.py:70-73), weighted by sqrt(0.2 * w_lc / (H_l W_l)) and concatenated with the image / sqrt(D) into one row V, so that
+    ||V_q - V_n||^2 is the distance and the [Q, N] search is one GEMM.  Needs w >= 0 (true for the vendored vgg.pth).  Returns
+    rows(images [n,3,H,W] fp32) -> [n, K] fp32 and search(q_rows, bank_rows) -> (dist [Q], idx [Q]).  Separates the algorithmic speed-up
+    (features once per image instead of once per pair: ~1 800 x at configs[2]) from the hardware one."""
+    import torch.nn.functional as F
+    w = [torch.from_numpy(vgg_sd["%d.weight" % k]) for k in _VGG_KEYS]
+    b = [torch.from_numpy(vgg_sd["%d.bias" % k]) for k in _VGG_KEYS]
+    lw = [torch.from_numpy(lin[i].reshape(-1).copy()).clamp_min(0.0) for i in range(5)]
+    shift = torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1)
+    scale = torch.tensor([.458, .448, .450]).view(1, 3, 1, 1)
+
+    def rows(x):
+        with torch.no_grad():
+            n = x.shape[0]
+            parts = [x.reshape(n, -1) / float(x[0].numel()) ** 0.5]
+            h, ci, tap = (x - shift) / scale, 0, 0
+            for v in _VGG_CFG:
+                if v == "M":
+                    h = F.max_pool2d(h, 2, 2)
+                    continue
+                h = F.relu(F.conv2d(h, w[ci], b[ci], padding=1))
+                if ci in _TAP_AFTER:
+                    nf = torch.sqrt(torch.sum(h ** 2, dim=1, keepdim=True))
+                    coef = torch.sqrt(0.2 * lw[tap] / float(h.shape[2] * h.shape[3])).view(1, -1, 1, 1)
+                    parts.append((h / (nf + 1e-10) * coef).reshape(n, -1))
+                    tap += 1
+                ci += 1
+            return torch.cat(parts, dim=1)
+
+    def search(q_rows, bank_rows):
+        with torch.no_grad():
+            d = (q_rows ** 2).sum(1, keepdim=True) + (bank_rows ** 2).sum(1)[None, :] - 2.0 * (q_rows @ bank_rows.t())
+            best, where = torch.min(d.clamp_min(0.0), dim=1)
+            return best, where
+
+    return rows, search

@@ -1,0 +1,76 @@
+"""GPU: the kernels the product runs against their simpler siblings, bit for bit (the software-pipelined main loop of
+gl_pair256.h places its fragment reads and waits by hand; keep a check against the plainly written kernels).  The siblings exist only in
+the tuning build (libganleaks_hip_tuning.so, -DGL_TUNING), which is loaded in a child process through $GANLEAKS_LIB:
+
+  int8 L2 search    : round-1 kernel (variant 0) == pipelined kernel (variant 1; what the shipped library runs) -- exact integers
+  fp16 LPIPS search : persistent cluster kernel (3; shipped) == persistent kernel without clusters (5; what a device with fewer than
+                      256 CUs gets): the same K segments and totals, so the same bits on any device
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import gpu_common  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import ganleaks_amd as gl
+from ganleaks_amd import _lib
+from ganleaks_amd.attack import Bank, knn_keys
+assert _lib.LIB_PATH.endswith("libganleaks_hip_tuning.so")
+ctx = gl.Context.get()
+rng = np.random.default_rng(5)
+out = {}
+# int8: 2100 x 8200 rows of 3 x 32 x 32 codes (ragged last tiles; enough 256-tiles for the large-tile kernel)
+bank = Bank.from_images(rng.integers(0, 256, size=(8200, 3, 32, 32), dtype=np.uint8), ctx)
+q = Bank.from_images(rng.integers(0, 256, size=(2100, 3, 32, 32), dtype=np.uint8), ctx)
+keys = {}
+for v in (0, 1, 4, 2):
+    os.environ["GL_PAIR_VARIANT"] = str(v)
+    keys[v] = knn_keys(bank, q)[0].numpy().copy()
+out["l2_equal"] = [bool(np.array_equal(keys[0], keys[v])) for v in (1, 4, 2)]
+# fp16 search rows: K = 2 segments + a ragged one (2048 slices of 64 halves per segment)
+import ctypes
+p = ctypes.c_void_p
+K = 64 * (2 * 2048 + 100)
+nb, nq = 700, 600
+bv = ctx.to_device((rng.standard_normal((nb, K)) * 40).astype(np.float16))
+qv = ctx.to_device((rng.standard_normal((nq, K)) * 40).astype(np.float16))
+bn = ctx.to_device((bv.numpy().astype(np.float32) ** 2).sum(1).astype(np.float32) / 16384.0 ** 2)
+qn = ctx.to_device((qv.numpy().astype(np.float32) ** 2).sum(1).astype(np.float32) / 16384.0 ** 2)
+fk = {}
+for v in (3, 5, 1):
+    os.environ["GL_PAIR_VARIANT"] = str(v)
+    k = ctx.empty((nq,), np.uint64)
+    _lib.check(ctx.lib.gl_keys_init(ctx.handle, p(k.ptr), nq))
+    _lib.check(ctx.lib.gl_feat_knn_h1(ctx.handle, p(bv.ptr), p(bn.ptr), nb, 0, p(qv.ptr), p(qn.ptr), nq, K, p(k.ptr)))
+    fk[v] = k.numpy().copy()
+out["feat_cluster_equals_plain_persistent"] = bool(np.array_equal(fk[3], fk[5]))
+d3 = (fk[3] >> np.uint64(32)).astype(np.uint32).view(np.float32)
+d1 = (fk[1] >> np.uint64(32)).astype(np.uint32).view(np.float32)
+out["feat_unsegmented_rel_diff"] = float(np.max(np.abs(d3 - d1) / np.maximum(d3, 1e-30)))
+out["feat_idx_equal_unsegmented"] = bool(np.array_equal(fk[3] & np.uint64(0xFFFFFFFF), fk[1] & np.uint64(0xFFFFFFFF)))
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_shipped_kernels_match_their_plain_siblings_bit_for_bit():
+    tuning = os.path.join(ROOT, "gan-leaks_amd", "libganleaks_hip_tuning.so")
+    if not os.path.exists(tuning):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "gan-leaks_amd", "csrc"), "-j8", "tuning"], check=True)
+    env = dict(os.environ, GANLEAKS_LIB=tuning)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = [l for l in r.stdout.decode().splitlines() if l.startswith("RESULT ")][-1]
+    out = json.loads(line[7:])
+    assert out["l2_equal"] == [True, True, True], out
+    assert out["feat_cluster_equals_plain_persistent"] is True, out
+    assert out["feat_unsegmented_rel_diff"] < 1e-4 and out["feat_idx_equal_unsegmented"], out

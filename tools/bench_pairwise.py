@@ -12,6 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the GL_PAIR_VARIANT switch and the experiment kernels exist only in the tuning build (make -C gan-leaks_amd/csrc tuning)
+os.environ.setdefault("GANLEAKS_LIB", os.path.join(ROOT, "gan-leaks_amd", "libganleaks_hip_tuning.so"))
 
 
 def main():

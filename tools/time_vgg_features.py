@@ -8,6 +8,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if any(k in os.environ for k in ("GL_TAP_FUSE", "GL_H3_HALO", "GL_H3_TILE128")):      # tuning switches exist only in the tuning build
+    os.environ.setdefault("GANLEAKS_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gan-leaks_amd", "libganleaks_hip_tuning.so"))
 import ganleaks_amd as gl  # noqa: E402
 from ganleaks_amd.lpips import LpipsModel  # noqa: E402
 
