@@ -111,6 +111,7 @@ SIGNATURES = {
     "gl_lpips_set_lin": (_i, [_p, _i, _p]),
     "gl_lpips_set_chunk": (_i, [_p, _i64]),
     "gl_lpips_set_precision": (_i, [_p, _i]),
+    "gl_lpips_set_calibration": (_i, [_p, _i]),
     "gl_lpips_feature_dim": (_i64, [_i, _i]),
     "gl_lpips_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_lpips_features_f32": (_i, [_p, _p, _i64, _i, _i, _p, _p]),

@@ -19,6 +19,7 @@
 #include "gl_pair256.h"
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -309,14 +310,13 @@ __device__ __forceinline__ float conv1_tap(float v, int c, const float (*)[256],
 
 template <typename T, bool SPLIT>
 __global__ void __launch_bounds__(256, 3) vgg_conv1_kernel(const T *__restrict__ img, int n, int H, int W, const float *__restrict__ wpack,
-                                                           const float *__restrict__ bias, char *__restrict__ out, int *__restrict__ sat_flag)
+                                                           const float *__restrict__ bias, char *__restrict__ out, int *__restrict__ sat_flag, float act)
 {
     typedef float v16f __attribute__((ext_vector_type(16)));
     typedef _Float16 v4h __attribute__((ext_vector_type(4)));
     constexpr int kRow = 272;                                   // bytes of LDS per position (256 + padding)
     __shared__ float lut[3][256];                               // code -> ((2 code / 255 - 1) - shift_c) / scale_c * act (attack_models/utils.py:82)
     __shared__ __attribute__((aligned(16))) char turn[4][32 * kRow];
-    const float act = SPLIT ? kVggAct : 1.0f;
 #pragma unroll
     for (int c = 0; c < 3; ++c)
         lut[c][threadIdx.x] = __fdiv_rn(__fsub_rn((float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0), c_shift[c]), c_scale[c]) * act;
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(256) maxpool2_split_kernel(const char *__restr
 // in the epilogue and one taken here from the stored activation give the same bits: per 16-channel tile, 4 groups of 4 consecutive
 // channels, each an fmaf chain from 0, combined as (g0 + g1) + (g2 + g3); then a balanced binary tree over the tiles.  A lane owns 8
 // channels = 2 groups; lanes 2 t and 2 t + 1 hold tile t.
-constexpr float kTapEps = 1e-10f * kVggAct;
+constexpr float kTapEps1 = 1e-10f;          // normalize_tensor's eps (util/util.py:72); activations stored as A f use A eps: (A f) / (|A f| + A eps) = f / (|f| + eps)
 __device__ __forceinline__ float tap_sumsq8(const float (&v)[8])
 {
     float a = 0.0f, b = 0.0f;
@@ -482,7 +482,7 @@ __device__ __forceinline__ float tap_sumsq_across(float s)
 // 512 / C positions per pass with 2 KiB of contiguous reads and C * 2 (or 4) bytes of contiguous writes per position.
 template <bool H1, int C>
 __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__restrict__ f, int64_t n, int HW, const float *__restrict__ coef,
-                                                              char *__restrict__ V, int64_t ldv_bytes, int64_t off)
+                                                              char *__restrict__ V, int64_t ldv_bytes, int64_t off, float tap_eps)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr int G = C / 8;            // lanes per position
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
         }
         ss = tap_sumsq_across<G>(ss);
         if (!live) continue;
-        const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), kTapEps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
+        const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), tap_eps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
         const int64_t im = pos / HW;
         char *row = V + im * ldv_bytes;
         const int64_t k = off + (pos - im * HW) * C + cb * 8;
@@ -537,7 +537,7 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
 // -> the pooled activation.  The activation (1 MB per image at relu1_2) is read once instead of twice.
 template <bool H1, int C>
 __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *__restrict__ f, int64_t n, int H, int W, const float *__restrict__ coef,
-                                                                   char *__restrict__ V, int64_t ldv_bytes, int64_t off, char *__restrict__ pooled)
+                                                                   char *__restrict__ V, int64_t ldv_bytes, int64_t off, char *__restrict__ pooled, float tap_eps)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr int G = C / 8;            // lanes per window
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
             }
             ss = tap_sumsq_across<G>(ss);
             if (!live) continue;
-            const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), kTapEps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
+            const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), tap_eps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
             char *row = V + im * ldv_bytes;
             const int64_t k = off + pin * C + cb * 8;
             h8 oh, ol;
@@ -606,26 +606,26 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
 int stream_blocks(int64_t items);
 
 template <bool H1>
-void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, const float *coef, char *V, int64_t ldv, int64_t off)
+void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, const float *coef, char *V, int64_t ldv, int64_t off, float eps)
 {
     const dim3 grid((unsigned)stream_blocks(n * HW * (C / 8)));
     switch (C) {
-    case 64: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
-    case 128: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
-    case 256: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
-    default: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off); break;
+    case 64: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
+    case 128: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
+    case 256: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
+    default: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
     }
 }
 
 template <bool H1>
-void launch_tap_pool_split(hipStream_t st, const char *f, int64_t n, int H, int W, int C, const float *coef, char *V, int64_t ldv, int64_t off, char *pooled)
+void launch_tap_pool_split(hipStream_t st, const char *f, int64_t n, int H, int W, int C, const float *coef, char *V, int64_t ldv, int64_t off, char *pooled, float eps)
 {
     const dim3 grid((unsigned)stream_blocks(n * (H / 2) * (W / 2) * (C / 8)));
     switch (C) {
-    case 64: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
-    case 128: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
-    case 256: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
-    default: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled); break;
+    case 64: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
+    case 128: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
+    case 256: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
+    default: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
     }
 }
 
@@ -1184,6 +1184,13 @@ struct gl_lpips {
     int precision;
     float *wsplit[kNumConv], *scale_h3[kNumConv], *bias_h3[kNumConv];
     int wexp[kNumConv];
+    // the output of convolution i is stored as (value * act[i]) in the split layout; act[i] = 2^aexp[i], chosen per layer by a calibration
+    // pass on fixed synthetic images the first time the split path runs (lp_calibrate), kVggAct before that.  Powers of two: a value's halves
+    // only move in exponent, so wherever nothing clamps or falls into the fp16 subnormals the results do not depend on the choice.
+    float act[kNumConv];
+    std::vector<float> bias_host[kNumConv];
+    bool calibrated, calibrate;
+    unsigned *calib_max;      // device, kNumConv words: max |activation| per layer as float bits (set only during the calibration pass)
     // workspace for `chunk` images of H x W
     int64_t chunk, ws_imgs;
     int ws_H, ws_W;
@@ -1235,6 +1242,119 @@ int stream_blocks(int64_t items)
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// max |x| over an fp32 activation tensor (non-negative after ReLU; the bits of a non-negative float order like unsigned integers)
+__global__ void __launch_bounds__(256) absmax_f32_kernel(const float *__restrict__ x, int64_t count, unsigned *__restrict__ out)
+{
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+// (re)build the split path's epilogue constants from the current act[]: acc = 2^wexp * act_in * conv  ->  stored out = acc * scale + shift with
+// scale = act_out / (2^wexp * act_in) and shift = bias * act_out  (all powers of two times the fp32 bias: exact)
+int lp_apply_scales(gl_lpips *l)
+{
+    for (int ci = 0; ci < kNumConv; ++ci) {
+        if (!l->have_w[ci]) continue;
+        const int co_n = kCout[ci];
+        const float a_in = ci == 0 ? 1.0f : l->act[ci - 1], a_out = l->act[ci];
+        std::vector<float> sc(co_n, std::ldexp(1.0f, -l->wexp[ci]) * (a_out / a_in)), bh(co_n);
+        for (int c = 0; c < co_n; ++c) bh[c] = l->bias_host[ci][c] * a_out;
+        int rc = lp_upload(l->ctx, &l->scale_h3[ci], sc);
+        if (rc == GL_OK) rc = lp_upload(l->ctx, &l->bias_h3[ci], bh);
+        if (rc != GL_OK) return rc;
+    }
+    return GL_OK;
+}
+
+template <typename T>
+int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, void *V_dev, float *norms_dev, int fmt);
+
+// Per-layer activation scales for the split path.  The fp32 pipeline runs once on 16 fixed synthetic 64 x 64 images (smooth fields, uniform
+// noise, flat black / white, stripes and a checkerboard, smooth + noise: generated here from a fixed LCG, so every context of every process
+// derives the same scales from the same weights -- a shard's features do not depend on which images it happened to see first), the largest
+// activation of every layer is taken, and act[i] = the power of two that puts it in [1024, 2048): 32 - 64 x of headroom below the fp16
+// maximum for images that excite a layer more than the calibration set does (a clamp is still counted, gl_ctx_h3_saturations, and the
+// Python callers then redo the pass with fp32 products), and full 22-bit operands for every value above ~6e-5 of that maximum.
+int lp_calibrate(gl_lpips *l)
+{
+    gl_ctx *ctx = l->ctx;
+    constexpr int N = 16, R = 64, D = 3 * R * R;
+    std::vector<uint8_t> img((size_t)N * D);
+    uint32_t lcg = 0x9E3779B9u;
+    auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (lcg >> 8) & 0xFFFFu; };       // 16 bits
+    for (int i = 0; i < N; ++i) {
+        float grid[3][9][9];
+        for (auto &c : grid) for (auto &r : c) for (float &v : r) v = (float)(rnd() & 255u);
+        for (int c = 0; c < 3; ++c)
+            for (int y = 0; y < R; ++y)
+                for (int x = 0; x < R; ++x) {
+                    const int gy = y / 8, gx = x / 8;
+                    const float fy = (y % 8) / 8.0f, fx = (x % 8) / 8.0f;
+                    const float smooth = (grid[c][gy][gx] * (1 - fx) + grid[c][gy][gx + 1] * fx) * (1 - fy) + (grid[c][gy + 1][gx] * (1 - fx) + grid[c][gy + 1][gx + 1] * fx) * fy;
+                    const float noise = (float)(rnd() & 255u);
+                    float v;
+                    switch (i % 8) {
+                    case 0: case 1: v = smooth; break;
+                    case 2: case 3: v = noise; break;
+                    case 4: v = i < 8 ? 0.0f : 255.0f; break;
+                    case 5: v = ((i < 8 ? x : y) / (1 + c)) % 2 ? 255.0f : 0.0f; break;
+                    case 6: v = ((x / 4 + y / 4) % 2) ? 255.0f : 0.0f; break;
+                    default: v = 0.6f * smooth + 0.4f * noise; break;
+                    }
+                    img[(size_t)i * D + ((size_t)c * R + y) * R + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                }
+    }
+    int64_t K_lp = 0;
+    { int h = R; for (int t = 0; t < 5; ++t) { K_lp += (int64_t)kTapC[t] * h * h; h /= 2; } }
+    const int64_t K = K_lp + D;
+    uint8_t *img_dev = nullptr;
+    float *V = nullptr, *norms = nullptr;
+    int rc = GL_OK;
+    const int saved_precision = l->precision;
+    const int64_t saved_chunk = l->chunk;
+    unsigned host_max[kNumConv];
+    GL_HIP(hipMalloc((void **)&img_dev, img.size()));
+    if (hipMalloc((void **)&V, (size_t)N * K * 4) != hipSuccess || hipMalloc((void **)&norms, N * 4) != hipSuccess ||
+        hipMalloc((void **)&l->calib_max, kNumConv * sizeof(unsigned)) != hipSuccess) {
+        gl_set_error("lp_calibrate: out of device memory");
+        rc = GL_ERR_HIP;
+    }
+    if (rc == GL_OK && (hipMemcpyAsync(img_dev, img.data(), img.size(), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                        hipMemsetAsync(l->calib_max, 0, kNumConv * sizeof(unsigned), ctx->stream) != hipSuccess)) {
+        gl_set_error("lp_calibrate: upload failed");
+        rc = GL_ERR_HIP;
+    }
+    if (rc == GL_OK) {
+        l->precision = 0;
+        l->chunk = N;
+        rc = lpips_features_impl<uint8_t>(l, img_dev, N, R, R, V, norms, 0);
+        l->precision = saved_precision;
+        l->chunk = saved_chunk;
+    }
+    if (rc == GL_OK && (hipMemcpyAsync(host_max, l->calib_max, sizeof(host_max), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        gl_set_error("lp_calibrate: read-back failed");
+        rc = GL_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(img_dev); (void)hipFree(V); (void)hipFree(norms); (void)hipFree(l->calib_max);
+    l->calib_max = nullptr;
+    // the calibration pass sized the workspace for 16 small images: let the next call size it for its own
+    if (rc != GL_OK) return rc;
+    for (int ci = 0; ci < kNumConv; ++ci) {
+        float mx;
+        memcpy(&mx, &host_max[ci], 4);
+        int e = 2;                                            // a dead layer keeps the default
+        if (mx > 0.0f && std::isfinite(mx)) e = (int)std::floor(std::log2(2047.0f / mx));
+        e = e > 40 ? 40 : (e < -40 ? -40 : e);
+        l->act[ci] = std::ldexp(1.0f, e);
+    }
+    return lp_apply_scales(l);
+}
+
 template <typename T>
 int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, void *V_dev, float *norms_dev, int fmt)
 {
@@ -1248,7 +1368,13 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
     if (n == 0) return GL_OK;
     GL_REQUIRE(img_dev && V_dev && norms_dev, "gl_lpips_features: NULL device pointer");
     gl_ctx *ctx = l->ctx;
-    int rc = lp_workspace(l, n, H, W);
+    int rc = GL_OK;
+    if (l->precision == 1 && !l->calibrated) {
+        l->calibrated = true;                                 // (the calibration pass comes back through this function with fp32 products)
+        rc = lp_calibrate(l);
+        if (rc != GL_OK) { l->calibrated = false; return rc; }
+    }
+    rc = lp_workspace(l, n, H, W);
     if (rc != GL_OK) return rc;
     const int64_t D = 3ll * H * W;
     int64_t K_lp = 0;
@@ -1294,12 +1420,16 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 const unsigned nb = (unsigned)std::min<int64_t>(gl_ceil_div(m * h * w, 128), (int64_t)ctx->num_cu * 8);
                 if (h3)
                     hipLaunchKernelGGL((vgg_conv1_kernel<T, true>), dim3(nb), dim3(256), 0, ctx->stream, img_dev + i0 * D, (int)m, h, w, l->w[0], l->bias[0],
-                                       reinterpret_cast<char *>(bufs[which]), ctx->h3_sat);
+                                       reinterpret_cast<char *>(bufs[which]), ctx->h3_sat, l->act[0]);
                 else
                     hipLaunchKernelGGL((vgg_conv1_kernel<T, false>), dim3(nb), dim3(256), 0, ctx->stream, img_dev + i0 * D, (int)m, h, w, l->w[0], l->bias[0],
-                                       reinterpret_cast<char *>(bufs[which]), ctx->h3_sat);
+                                       reinterpret_cast<char *>(bufs[which]), ctx->h3_sat, 1.0f);
                 GL_LAUNCH_CHECK();
                 cur = bufs[which];
+                if (!h3 && l->calib_max) {
+                    hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)stream_blocks(m * h * w * 64)), dim3(256), 0, ctx->stream, cur, m * h * w * 64, l->calib_max);
+                    GL_LAUNCH_CHECK();
+                }
                 which ^= 1;
                 continue;
             }
@@ -1321,7 +1451,7 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                     // tap + 2x2 max-pool in the convolution's epilogue: the full-resolution activation is never stored
                     const int C = kCout[ci];
                     p.tap_V = Vc; p.tap_coef = l->ws_coef + coef_off; p.tap_ldv = ldv; p.tap_off = off; p.tap_fmt = fmt ? 1 : 0;
-                    p.tap_pool = reinterpret_cast<char *>(bufs[which]); p.tap_scale = kVScale; p.tap_eps = kTapEps;
+                    p.tap_pool = reinterpret_cast<char *>(bufs[which]); p.tap_scale = kVScale; p.tap_eps = kTapEps1 * l->act[ci];
                     rc = gl_launch_gather_conv_h3(ctx, p, 1);
                     if (rc != GL_OK) return rc;
                     off += (int64_t)C * h * w;
@@ -1338,15 +1468,20 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             if (rc != GL_OK) return rc;
             cur = bufs[which];
             which ^= 1;
+            if (!h3 && l->calib_max) {
+                hipLaunchKernelGGL(absmax_f32_kernel, dim3((unsigned)stream_blocks(m * h * w * kCout[ci])), dim3(256), 0, ctx->stream, cur, m * h * w * kCout[ci],
+                                   l->calib_max + ci);
+                GL_LAUNCH_CHECK();
+            }
             if (kAfter[ci] == 2 && h3) {
                 // tap + 2x2 max-pool in one pass over the activation
                 const int C = kCout[ci];
                 if (fmt)
                     launch_tap_pool_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vc, ldv, off,
-                                                reinterpret_cast<char *>(bufs[which]));
+                                                reinterpret_cast<char *>(bufs[which]), kTapEps1 * l->act[ci]);
                 else
                     launch_tap_pool_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vc, ldv, off,
-                                                 reinterpret_cast<char *>(bufs[which]));
+                                                 reinterpret_cast<char *>(bufs[which]), kTapEps1 * l->act[ci]);
                 GL_LAUNCH_CHECK();
                 off += (int64_t)C * h * w;
                 coef_off += C;
@@ -1359,9 +1494,9 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 const int C = kCout[ci];
                 const dim3 tg((unsigned)stream_blocks(m * h * w * 64));
                 if (h3 && fmt)
-                    launch_tap_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
+                    launch_tap_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off, kTapEps1 * l->act[ci]);
                 else if (h3)
-                    launch_tap_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
+                    launch_tap_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off, kTapEps1 * l->act[ci]);
                 else if (fmt)
                     hipLaunchKernelGGL(lpips_tap_kernel<true>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
                 else
@@ -1424,7 +1559,8 @@ int gl_lpips_create(gl_ctx *ctx, gl_lpips **out)
     GL_REQUIRE(ctx && out, "gl_lpips_create: NULL argument");
     gl_lpips *l = new gl_lpips();
     l->ctx = ctx;
-    for (int i = 0; i < kNumConv; ++i) { l->w[i] = l->bias[i] = nullptr; l->have_w[i] = false; l->wsplit[i] = l->scale_h3[i] = l->bias_h3[i] = nullptr; l->wexp[i] = 0; }
+    for (int i = 0; i < kNumConv; ++i) { l->w[i] = l->bias[i] = nullptr; l->have_w[i] = false; l->wsplit[i] = l->scale_h3[i] = l->bias_h3[i] = nullptr; l->wexp[i] = 0; l->act[i] = kVggAct; }
+    l->calibrated = false; l->calibrate = true; l->calib_max = nullptr;
     l->precision = 1;
     for (int i = 0; i < 5; ++i) { l->lin[i] = nullptr; l->have_lin[i] = false; }
     l->ones = nullptr;
@@ -1463,6 +1599,16 @@ int gl_lpips_set_precision(gl_lpips *l, int mode)
     GL_REQUIRE(l && (mode == 0 || mode == 1), "gl_lpips_set_precision: mode must be 0 or 1");
     l->precision = mode;
     return GL_OK;
+}
+
+int gl_lpips_set_calibration(gl_lpips *l, int enabled)
+{
+    gl_make_current(l ? l->ctx : nullptr);
+    GL_REQUIRE(l && (enabled == 0 || enabled == 1), "gl_lpips_set_calibration: enabled must be 0 or 1");
+    l->calibrate = enabled != 0;
+    for (int i = 0; i < kNumConv; ++i) l->act[i] = kVggAct;
+    l->calibrated = !l->calibrate;                    // disabled: the defaults stand; enabled: the next split-path call calibrates
+    return lp_apply_scales(l);
 }
 
 int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *bias)
@@ -1504,14 +1650,14 @@ int gl_lpips_set_conv(gl_lpips *l, int conv_index, const float *w, const float *
         std::copy(pk.begin(), pk.end(), padded.begin());
         gl_split_weights_host(padded.data(), rows128, Kl, std::ldexp(1.0f, e), split.data());
         rc = lp_upload(l->ctx, &l->wsplit[conv_index], split);
-        std::vector<float> sc(co_n, std::ldexp(1.0f, -e)), bh(co_n);
-        for (int c = 0; c < co_n; ++c) bh[c] = bias[c] * kVggAct;
-        if (rc == GL_OK) rc = lp_upload(l->ctx, &l->scale_h3[conv_index], sc);
-        if (rc == GL_OK) rc = lp_upload(l->ctx, &l->bias_h3[conv_index], bh);
         if (rc != GL_OK) return rc;
+        l->bias_host[conv_index].assign(bias, bias + co_n);
     }
     l->have_w[conv_index] = true;
-    return GL_OK;
+    // new weights: back to the default activation scales until the next split-path call calibrates again
+    for (int i = 0; i < kNumConv; ++i) l->act[i] = kVggAct;
+    l->calibrated = !l->calibrate;
+    return lp_apply_scales(l);
 }
 
 int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w)

@@ -112,6 +112,11 @@ class LpipsModel:
         check(self.ctx.lib.gl_lpips_set_precision(self._handle, int(mode)))
         self._precision = int(mode)
 
+    def set_calibration(self, enabled):
+        """split-fp16 mode: True (default) = per-layer power-of-two activation scales from a calibration pass over fixed synthetic images
+        (include/ganleaks.h gl_lpips_set_calibration); False = the fixed factor 4 of rounds 1-2"""
+        check(self.ctx.lib.gl_lpips_set_calibration(self._handle, 1 if enabled else 0))
+
     def set_chunk(self, images_per_pass):
         check(self.ctx.lib.gl_lpips_set_chunk(self._handle, int(images_per_pass)))
 

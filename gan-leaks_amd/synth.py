@@ -94,21 +94,40 @@ VGG16_CONV_KEYS = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]     # torchvi
 LPIPS_CHANNELS = [64, 128, 256, 512, 512]                               # taps relu1_2, 2_2, 3_3, 4_3, 5_3
 
 
-def vgg16_state_dict(seed=7, bias_std=0.05):
+# imagenet_like=True: how much every layer amplifies its input (second-moment gain of the Kaiming-normal layer times this factor).  The
+# cumulative products -- 2, 8, 24, 72, 180, 360, 360, 180, 90, 22, 11, 2.8, 0.35 -- follow the rise and fall of the activation
+# magnitudes of a trained VGG16 (O(1) at conv1_1, hundreds in conv3 / conv4, back to O(1) at conv5_3); with the per-channel spread below
+# activations span roughly 1e-3 ... 3e4.
+VGG16_LAYER_GAINS = [2.0, 4.0, 3.0, 3.0, 2.5, 2.0, 1.0, 0.5, 0.5, 0.25, 0.5, 0.25, 0.125]
+
+
+def vgg16_state_dict(seed=7, bias_std=0.05, imagenet_like=False):
     """Random VGG16 conv weights under torchvision's `vgg16().features` key names ({idx}.weight
     [Cout,Cin,3,3], {idx}.bias).  The ImageNet weights the reference downloads
     (attack_models/lpips_pytorch/models/pretrained_networks.py:99) are not available offline
-    (SURVEY.md D10); Kaiming-normal weights keep activations O(1) through the 13 layers."""
+    (SURVEY.md D10); Kaiming-normal weights keep activations O(1) through the 13 layers.
+
+    imagenet_like=True gives the weights the DYNAMIC RANGE of a trained network instead (not its features): every layer's rows are scaled by
+    VGG16_LAYER_GAINS[l] and by a per-channel factor drawn log-uniformly from [1/16, 16] (normalised to unit mean square, so the layer gain
+    stays what the table says), biases scale with the layer's activation level.  Used to check that the split-fp16 VGG16 path neither
+    saturates nor loses accuracy when activations are far from O(1) (tests/test_gpu_lpips.py)."""
     rng = np.random.default_rng(seed)
     sd = {}
     cin = 3
     it = iter(VGG16_CONV_KEYS)
-    for v in VGG16_CFG:
-        if v == "M":
-            continue
+    level = 1.0
+    for li, v in enumerate([c for c in VGG16_CFG if c != "M"]):
         k = next(it)
-        sd[f"{k}.weight"] = rng.normal(0.0, np.sqrt(2.0 / (cin * 9)), size=(v, cin, 3, 3)).astype(np.float32)
-        sd[f"{k}.bias"] = rng.normal(0.0, bias_std, size=v).astype(np.float32)
+        w = rng.normal(0.0, np.sqrt(2.0 / (cin * 9)), size=(v, cin, 3, 3))
+        b = rng.normal(0.0, bias_std, size=v)
+        if imagenet_like:
+            ch = np.exp(rng.uniform(np.log(1 / 16.0), np.log(16.0), size=v))
+            ch /= np.sqrt(np.mean(ch ** 2))
+            w *= (VGG16_LAYER_GAINS[li] * ch)[:, None, None, None]
+            level *= VGG16_LAYER_GAINS[li]
+            b *= level * ch
+        sd[f"{k}.weight"] = w.astype(np.float32)
+        sd[f"{k}.bias"] = b.astype(np.float32)
         cin = v
     return sd
 

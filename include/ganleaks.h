@@ -264,6 +264,12 @@ int gl_lpips_set_lin(gl_lpips *l, int layer, const float *w_host);
 int gl_lpips_set_chunk(gl_lpips *l, int64_t images_per_pass);
 /* arithmetic of the 13 VGG16 convolutions: 1 (default) = split-fp16 (three fp16 MFMAs per product), 0 = fp32 MFMA */
 int gl_lpips_set_precision(gl_lpips *l, int mode);
+/* split-fp16 mode only: how activations are scaled into the fp16 halves.  1 (default) = one power of two per layer, chosen when the split path
+ * first runs from a calibration pass of the fp32 pipeline over 16 fixed synthetic images (the same scales in every process and context for the
+ * same weights; the layer's largest calibration activation lands in [1024, 2048) of the fp16 range 65504: 32-64 x headroom, full 22-bit
+ * operands down to ~6e-5 of that maximum); 0 = the fixed factor 4 for every layer (rounds 1-2: fine while activations are O(1), saturates
+ * beyond 16 376).  A store that still has to clamp is counted either way (gl_ctx_h3_saturations). */
+int gl_lpips_set_calibration(gl_lpips *l, int enabled);
 /* length of V for H x W images: sum_l C_l H_l W_l + 3 H W  (512 000 at 64 x 64); -1 if H or W is not a multiple of 16 */
 int64_t gl_lpips_feature_dim(int H, int W);
 /* images [n][3][H][W] (8-bit codes, or fp32 in [-1,1]) -> V_dev [n][K] feature rows of 4*K bytes each (opaque: every 32 values are

@@ -55,7 +55,7 @@ def test_bench_line_with_secondary_measurements():
     assert fo["kind"] == "port" and fo["cores"] >= 1 and fo["value"] > c["value"] and fo["idx_equal_gpu"] is True and fo["max_abs_dist_diff_vs_gpu"] < 1e-5
     assert s["algorithmic_speedup_on_cpu"] > 10 and s["speedup_vs_cpu_features_once"] > 1
     c0 = d["config0"]                            # BASELINE configs[0]: 256 x 1k, L2, CPU full run (median of 3) beside the device
-    assert "configs[0]" in c0["workload"] and c0["parity"]["idx_equal"] is True and c0["parity"]["max_abs_dist_err"] == 0.0
+    assert "configs[0]" in c0["workload"] and c0["parity"]["idx_equal"] is True and c0["parity"]["max_abs_dist_err"] < 1e-6
     assert c0["cpu_baseline"]["cores"] >= 1 and c0["cpu_baseline"]["value"] > 0 and "median of 3" in c0["cpu_baseline"]["sample"]
     f = d["secondary_fp32"]
     assert f["dtype"].startswith("f32") and f["roofline"]["peak"] == 157.3 and f["parity"]["idx_equal"] is True

@@ -301,6 +301,7 @@ def test_host_one_call_falls_back_when_split_fp16_saturates(gl, synth, lin):
     sd = {k: v.copy() for k, v in synth.vgg16_state_dict(7).items()}
     sd["0.weight"] *= 3.0e4
     hot = LpipsModel().load_state_dicts(sd, lin)
+    hot.set_calibration(False)           # the fixed activation scale of rounds 1-2: the calibrated scales adapt to such weights (test below)
     case = synth.attack_case(94, 48, 4, 3, 32, sigma=20.0)
     bank = np.ascontiguousarray(case["bank"])
     q = np.ascontiguousarray(np.concatenate([case["pos"], case["neg"]]))
@@ -381,3 +382,44 @@ def test_lattice_and_hilo_search_rows_agree(gl, synth, model, lin, oracle):
         model.features(qf, role="query", fmt="lattice")
     with pytest.raises(ValueError):
         feat_knn_keys(model.features(bank, role="bank", fmt="hilo"), model.features(q, role="query"))
+
+
+def test_split_path_on_weights_with_imagenet_like_dynamic_range(gl, synth, lin, oracle):
+    """every split-fp16 VGG16 result so far came from a Kaiming backbone with O(1) activations.  With weights that have the
+    dynamic range of a trained network (synth.vgg16_state_dict(imagenet_like=True): activations from ~1e-4 to ~6e3, layer levels rising to
+    hundreds and falling back) the split path must (a) actually run -- no saturation, no fallback to fp32 products -- and (b) stay fp32-class:
+    its error against the fp64 oracle at most 1.5 x the fp32-MFMA path's.  The per-layer activation scales come from the calibration pass
+    (gl_lpips_set_calibration); with the fixed scale of rounds 1-2 the same weights lose accuracy or clamp."""
+    import lpips_oracle
+    from ganleaks_amd import lpips as lp
+    from ganleaks_amd.lpips import LpipsModel
+    ctx = gl.Context.get()
+    sd = synth.vgg16_state_dict(7, imagenet_like=True)
+    lins = [lin["lin%d" % i] for i in range(5)]
+    rng = np.random.default_rng(12)
+    bank = np.concatenate([synth.lowpass_u8_images(61, 10, 32), rng.integers(0, 256, size=(6, 3, 32, 32), dtype=np.uint8)])      # smooth + noise images
+    q = synth.perturb_u8(62, bank[[0, 5, 11, 14]], 6.0)
+    f = lambda u: (2.0 * (u / 255.0) - 1.0).astype(np.float32)
+    ref = lpips_oracle.lpips_matrix(sd, lins, f(q), f(bank))                    # float64 [4, 16]
+    errs = {}
+    for precision in (1, 0):
+        m = LpipsModel().load_state_dicts(sd, lin)
+        m.set_precision(precision)
+        ctx.h3_saturations()
+        fb = m.features(bank)
+        got = np.stack([lp.rows_dist(fb, m.features(q[k:k + 1]))[0] for k in range(len(q))])
+        assert ctx.h3_saturations() == 0 and m._precision == precision, "the split path saturated on imagenet-like weights"
+        errs[precision] = float(np.abs(got.astype(np.float64) - ref).max())
+    print("lpips error vs fp64, imagenet-like weights: split %.3g, fp32 %.3g (values %.3g .. %.3g)" % (errs[1], errs[0], ref.min(), ref.max()))
+    assert errs[1] <= 1.5 * errs[0] + 2e-7, errs
+    assert errs[1] < 5e-6, errs
+    # calibration is a function of the weights alone: a second model, used in another order, gives the same bits
+    a = LpipsModel().load_state_dicts(sd, lin)
+    b = LpipsModel().load_state_dicts(sd, lin)
+    b.features(rng.integers(0, 256, size=(3, 3, 64, 64), dtype=np.uint8), role="bank")
+    va, vb = a.features(bank, role="bank"), b.features(bank, role="bank")
+    assert np.array_equal(va.V.numpy(), vb.V.numpy()) and np.array_equal(va.norms.numpy(), vb.norms.numpy())
+    # and the search on these weights agrees with the oracle's nearest neighbours
+    od, oi, _ = lpips_oracle.knn_l2_lpips(sd, lins, f(bank), f(q), 16)
+    d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=a)
+    assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
