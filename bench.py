@@ -182,8 +182,13 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
         log("[rank %d] l2-lpips: feature vectors need %.1f GB of HBM" % (rank, need_gb))
         bank_V = ctx.empty((n_loc, KF), row_dtype)
         bank_Vn = ctx.empty((n_loc,), np.float32)
-        q_V = ctx.empty((Q, KF), row_dtype)
-        q_Vn = ctx.empty((Q,), np.float32)
+        # N > 1 with the native communicator: the query features are sharded too (rank r featurises Q / N queries, two all-gathers);
+        # everything else keeps all queries replicated
+        q_shard = h1 and job.comm is not None and world > 1
+        q_per = -(-Q // world) if q_shard else Q
+        q_lo, q_hi = (min(rank * q_per, Q), min((rank + 1) * q_per, Q)) if q_shard else (0, Q)
+        q_V = ctx.empty((q_per * world if q_shard else Q, KF), row_dtype)
+        q_Vn = ctx.empty((q_per * world if q_shard else Q,), np.float32)
 
     stride = int(lib.gl_l2_row_stride(D))
     bank_u8 = ctx.empty((n_loc, D), np.uint8)
@@ -218,7 +223,14 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
         else:
             if h1:
                 check(lib.gl_lpips_lattice_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
-                check(lib.gl_lpips_lattice_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
+                if q_shard:
+                    if q_hi > q_lo:
+                        check(lib.gl_lpips_lattice_features_u8(lp_model._handle, p(q_dev.ptr + q_lo * D), q_hi - q_lo, 64, 64,
+                                                               p(q_V.ptr + q_lo * KF * 2), p(q_Vn.ptr + q_lo * 4)))
+                    job.comm.allgather_rows(q_V, q_per * KF * 2)
+                    job.comm.allgather_rows(q_Vn, q_per * 4)
+                else:
+                    check(lib.gl_lpips_lattice_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
             else:
                 check(lib.gl_lpips_features_u8(lp_model._handle, p(bank_u8.ptr), n_loc, 64, 64, p(bank_V.ptr), p(bank_Vn.ptr)))
                 check(lib.gl_lpips_features_u8(lp_model._handle, p(q_dev.ptr), Q, 64, 64, p(q_V.ptr), p(q_Vn.ptr)))
@@ -499,7 +511,7 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
                    "BASELINE configs[2]: DCGAN/WGAN-GP-64 generator -> 8-bit bank, 0.2*LPIPS+L2 1-NN (fbb default distance)",
                    "queries": Q, "bank": N,
                    "bank_used": n_eff, "batch_size": B, "image": "3x64x64", "parallelism": "bank sharded x%d (%s), queries replicated, "
-                   "all-reduce(min) of %d packed keys (%s)" % (world, shard_note, Q, {"native": "RCCL through the C ABI on the library's stream",
+                   "%sall-reduce(min) of %d packed keys (%s)" % (world, shard_note, "query features sharded + all-gathered, " if (lp_model is not None and q_shard) else "", Q, {"native": "RCCL through the C ABI on the library's stream",
                                                                                     "torch": "torch.distributed nccl", "gloo": "gloo through host memory"}.get(job.collective, ""))
                    if world > 1 else "single GPU",
                    "shard_rows": [int(bounds[r + 1] - bounds[r]) for r in range(world)]},

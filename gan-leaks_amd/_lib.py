@@ -51,6 +51,7 @@ SIGNATURES = {
     "gl_ctx_h3_saturations": (_i, [_p, ctypes.POINTER(_i64)]),
     "gl_malloc": (_i, [_p, _sz, _pp]),
     "gl_free": (_i, [_p, _p]),
+    "gl_ctx_trim": (_i, [_p]),
     "gl_memcpy_h2d": (_i, [_p, _p, _p, _sz]),
     "gl_memcpy_d2h": (_i, [_p, _p, _p, _sz]),
     "gl_memset": (_i, [_p, _p, _i, _sz]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "gl_comm_abort": (_i, [_p]),
     "gl_comm_rank": (_i, [_p, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "gl_allreduce_min_keys": (_i, [_p, _p, _i64]),
+    "gl_allgather_rows": (_i, [_p, _p, _p, _i64]),
     "gl_comm_group_start": (_i, []),
     "gl_comm_group_end": (_i, []),
 }
@@ -223,6 +225,10 @@ class Context:
 
     def sync(self):
         check(self.lib.gl_ctx_sync(self.handle))
+
+    def trim(self):
+        """return the large device blocks the context keeps for reuse (gl_free's arena, include/ganleaks.h) to the driver"""
+        check(self.lib.gl_ctx_trim(self.handle))
 
     def destroy(self):
         """release the stream and scratch of a context created with Context(device) (arrays and models built on it must be gone)"""
@@ -332,6 +338,15 @@ class Comm:
         n = int(np.prod(keys.shape, dtype=np.int64))
         check(self.ctx.lib.gl_allreduce_min_keys(self.handle, _p(keys.ptr), n))
         return keys
+
+    def allgather_rows(self, buf, bytes_per_rank):
+        """in place on the context's stream (asynchronous): block r of `buf` (bytes_per_rank bytes each, this rank's block already filled)
+        = rank r's block, for every rank"""
+        total = int(np.prod(buf.shape, dtype=np.int64)) * buf.dtype.itemsize
+        if bytes_per_rank * self.nranks > total:
+            raise ValueError("buffer of %d bytes cannot hold %d blocks of %d" % (total, self.nranks, bytes_per_rank))
+        check(self.ctx.lib.gl_allgather_rows(self.handle, _p(buf.ptr + self.rank * bytes_per_rank), _p(buf.ptr), int(bytes_per_rank)))
+        return buf
 
     def destroy(self):
         if getattr(self, "handle", None) is not None:

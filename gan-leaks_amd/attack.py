@@ -321,10 +321,12 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
     raise AssertionError("unreachable")
 
 
-def prepare_queries(queries, distance, ctx=None, lpips=None):
+def prepare_queries(queries, distance, ctx=None, lpips=None, comm=None):
     """the query side of attack() prepared once, for callers that search several banks (a sweep, the chunks of a sharded bank) or want
     the fallible part (uploads, VGG16 features) done before a collective: int8 rows for 'l2', LPIPS search rows for 'l2-lpips' when
-    they fit the streaming budget -- otherwise the images are returned as they are and attack() slices them itself."""
+    they fit the streaming budget -- otherwise the images are returned as they are and attack() slices them itself.
+    comm (a `_lib.Comm` of more than one rank; COLLECTIVE: every rank must call this with the same queries): the VGG16 features of 8-bit
+    queries are computed Q / nranks per rank and all-gathered (lpips.features_sharded) instead of all of them on every rank."""
     if isinstance(queries, Bank) or getattr(queries, "kind", None) == "feat" or not len(queries):
         return queries
     if distance == "l2-lpips":
@@ -332,6 +334,9 @@ def prepare_queries(queries, distance, ctx=None, lpips=None):
         model = lpips or _lp.default_model()
         if len(queries) * _feature_row_bytes(model.ctx, model, queries) > _budget_bytes():
             return queries
+        if (comm is not None and comm.nranks > 1 and model.search_rows == "fp16" and getattr(queries, "dtype", None) == np.uint8
+                and len(queries) >= 8 * comm.nranks):
+            return _lp.features_sharded(model, queries, comm)
         return model.features(queries, role=model.search_role("query"))
     return Bank.from_images(queries, ctx or Context.get(), keep_u8=True)
 

@@ -40,6 +40,24 @@ gl_prof_scope::~gl_prof_scope()
     ctx->prof_spans.push_back(span);
 }
 
+hipError_t gl_device_alloc(gl_ctx *ctx, void **out, size_t bytes)
+{
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        (void)hipGetLastError();
+        bool any;
+        {
+            std::lock_guard<std::mutex> lk(*ctx->arena_mu);
+            any = !ctx->arena_free.empty();
+        }
+        if (any) {
+            (void)gl_ctx_trim(ctx);
+            e = hipMalloc(out, bytes);
+        }
+    }
+    return e;
+}
+
 extern "C" {
 
 int gl_prof_enable(gl_ctx *ctx, int on)
@@ -118,6 +136,7 @@ int gl_ctx_create(int device, gl_ctx **out_ctx)
     c->num_cu = prop.multiProcessorCount;
     c->pair_scratch = nullptr;
     c->pair_scratch_bytes = 0;
+    c->arena_mu = new std::mutex();
     GL_HIP(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     GL_HIP(hipMalloc((void **)&c->zero_page, 4096));
@@ -140,7 +159,9 @@ int gl_ctx_destroy(gl_ctx *ctx)
     (void)hipFree(ctx->zero_page);
     (void)hipFree(ctx->h3_sat);
     (void)hipFree(ctx->pair_scratch);
+    (void)gl_ctx_trim(ctx);
     (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx->arena_mu;
     delete ctx;
     return GL_OK;
 }
@@ -181,6 +202,22 @@ int gl_ctx_h3_saturations(gl_ctx *ctx, int64_t *out_count)
     return GL_OK;
 }
 
+constexpr size_t kArenaMin = 256ull << 20;      // blocks below this go straight back to the driver
+
+int gl_ctx_trim(gl_ctx *ctx)
+{
+    gl_make_current(ctx);
+    GL_REQUIRE(ctx, "gl_ctx_trim: NULL ctx");
+    std::vector<std::pair<size_t, void *>> blocks;
+    {
+        std::lock_guard<std::mutex> lk(*ctx->arena_mu);
+        blocks.swap(ctx->arena_free);
+    }
+    if (!blocks.empty()) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &b : blocks) (void)hipFree(b.second);
+    return GL_OK;
+}
+
 int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev)
 {
     gl_make_current(ctx);
@@ -188,7 +225,26 @@ int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev)
     GL_HIP(hipSetDevice(ctx->device));
     *out_dev = nullptr;
     if (bytes == 0) return GL_OK;
-    GL_HIP(hipMalloc(out_dev, bytes));
+    if (bytes >= kArenaMin) {
+        std::lock_guard<std::mutex> lk(*ctx->arena_mu);
+        // the smallest kept block that holds the request without wasting more than an eighth of it
+        size_t best = ctx->arena_free.size();
+        for (size_t i = 0; i < ctx->arena_free.size(); ++i) {
+            const size_t have = ctx->arena_free[i].first;
+            if (have >= bytes && have - bytes <= bytes / 8 && (best == ctx->arena_free.size() || have < ctx->arena_free[best].first)) best = i;
+        }
+        if (best != ctx->arena_free.size()) {
+            *out_dev = ctx->arena_free[best].second;
+            ctx->arena_live.emplace_back(*out_dev, ctx->arena_free[best].first);
+            ctx->arena_free.erase(ctx->arena_free.begin() + (long)best);
+            return GL_OK;
+        }
+    }
+    GL_HIP(gl_device_alloc(ctx, out_dev, bytes));
+    if (bytes >= kArenaMin) {
+        std::lock_guard<std::mutex> lk(*ctx->arena_mu);
+        ctx->arena_live.emplace_back(*out_dev, bytes);
+    }
     return GL_OK;
 }
 
@@ -198,6 +254,15 @@ int gl_free(gl_ctx *ctx, void *dev)
     GL_REQUIRE(ctx, "gl_free: NULL ctx");
     if (!dev) return GL_OK;
     GL_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        std::lock_guard<std::mutex> lk(*ctx->arena_mu);
+        for (size_t i = 0; i < ctx->arena_live.size(); ++i)
+            if (ctx->arena_live[i].first == dev) {
+                ctx->arena_free.emplace_back(ctx->arena_live[i].second, dev);      // kept for the next request of this size (gl_ctx_trim releases)
+                ctx->arena_live.erase(ctx->arena_live.begin() + (long)i);
+                return GL_OK;
+            }
+    }
     GL_HIP(hipFree(dev));
     return GL_OK;
 }

@@ -27,6 +27,7 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -58,6 +59,7 @@ RcclApi *rccl()
         api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
         api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(sym("ncclCommAbort"));
         api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+        api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
         api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
         api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
@@ -182,6 +184,17 @@ int gl_allreduce_min_keys(gl_comm *c, uint64_t *keys_dev, int64_t nq)
     GL_RCCL_API(api);
     // in place, unsigned 64-bit minimum: smallest distance first, then smallest global index (torch.min's first occurrence, fbb.py:86)
     GL_RCCL(api, api->AllReduce(keys_dev, keys_dev, (size_t)nq, ncclUint64, ncclMin, c->comm, c->ctx->stream));
+    return GL_OK;
+}
+
+int gl_allgather_rows(gl_comm *c, const void *send_dev, void *recv_dev, int64_t bytes_per_rank)
+{
+    GL_REQUIRE(c && bytes_per_rank >= 0, "gl_allgather_rows: bad argument");
+    if (bytes_per_rank == 0) return GL_OK;
+    GL_REQUIRE(send_dev && recv_dev, "gl_allgather_rows: NULL device pointer");
+    gl_make_current(c->ctx);
+    GL_RCCL_API(api);
+    GL_RCCL(api, api->AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, ncclUint8, c->comm, c->ctx->stream));
     return GL_OK;
 }
 

@@ -22,6 +22,11 @@ struct gl_ctx {
     int num_cu;              // compute units of the device
     char *pair_scratch;      // lazily allocated workspace of the persistent pairwise kernel: per-workgroup fp32 totals + cluster counters
     size_t pair_scratch_bytes;
+    // arena: device blocks of >= 256 MiB that gl_free keeps for the next gl_malloc of (almost) the same size instead of returning them to the
+    // driver (allocating and freeing the 153 GiB of query rows of a 256 x 256 attack costs 2-7 s per call); gl_ctx_trim releases them
+    std::mutex *arena_mu;
+    std::vector<std::pair<size_t, void *>> arena_free;                 // (bytes, block) not in use
+    std::vector<std::pair<void *, size_t>> arena_live;                 // blocks handed out by gl_malloc that gl_free may keep
     bool prof_on;            // gl_prof_enable: bracket tagged kernel launches with HIP events
     std::vector<gl_prof_span> prof_spans;
     std::vector<hipEvent_t> prof_pool;
@@ -37,6 +42,9 @@ struct gl_prof_scope {
 };
 
 void gl_set_error(const char *fmt, ...);
+// hipMalloc for the library's own workspaces: when the device is out of memory, the context's cached arena blocks are released and the
+// allocation is tried once more
+hipError_t gl_device_alloc(gl_ctx *ctx, void **out, size_t bytes);
 
 #define GL_HIP(expr)                                                                         \
     do {                                                                                     \

@@ -284,16 +284,16 @@ int ensure_workspace(gl_dcgan *g, int64_t n)
     (void)hipFree(g->ws_qkv);
     g->ws_att = g->ws_qkv = nullptr;
     g->ws_chunk = 0;
-    GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)want * g->z_pad * 4));
+    GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_z, (size_t)want * g->z_pad * 4));
     int hw = 16;
     for (int l = 0; l < 4; ++l) {
-        GL_HIP(hipMalloc((void **)&g->ws_a[l], (size_t)want * hw * g->cout[l] * 4));
+        GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_a[l], (size_t)want * hw * g->cout[l] * 4));
         hw *= 4;
     }
-    GL_HIP(hipMalloc((void **)&g->ws_p, (size_t)want * 32 * 32 * 16 * g->nc * 4));
+    GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_p, (size_t)want * 32 * 32 * 16 * g->nc * 4));
     if (g->have_att) {
-        GL_HIP(hipMalloc((void **)&g->ws_att, (size_t)want * 256 * g->cout[2] * 4));
-        GL_HIP(hipMalloc((void **)&g->ws_qkv, (size_t)want * 256 * (g->cout[2] + g->cout[2] / 4) * 4));
+        GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_att, (size_t)want * 256 * g->cout[2] * 4));
+        GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_qkv, (size_t)want * 256 * (g->cout[2] + g->cout[2] / 4) * 4));
     }
     g->ws_chunk = want;
     return GL_OK;

@@ -1230,8 +1230,8 @@ int lp_workspace(gl_lpips *l, int64_t n, int H, int W)
     l->ws_a = l->ws_b = nullptr;
     l->ws_imgs = 0;
     const size_t px = (size_t)want * H * W;
-    GL_HIP(hipMalloc((void **)&l->ws_a, px * 64 * 4));      // largest activation: H x W x 64
-    GL_HIP(hipMalloc((void **)&l->ws_b, px * 64 * 4));
+    GL_HIP(gl_device_alloc(l->ctx, (void **)&l->ws_a, px * 64 * 4));      // largest activation: H x W x 64
+    GL_HIP(gl_device_alloc(l->ctx, (void **)&l->ws_b, px * 64 * 4));
     l->ws_imgs = want; l->ws_H = H; l->ws_W = W;
     return GL_OK;
 }
@@ -1757,7 +1757,7 @@ int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *ba
             GL_HIP(hipStreamSynchronize(ctx->stream));
             (void)hipFree(ctx->pair_scratch);
             ctx->pair_scratch = nullptr; ctx->pair_scratch_bytes = 0;
-            GL_HIP(hipMalloc((void **)&ctx->pair_scratch, need));
+            GL_HIP(gl_device_alloc(ctx, (void **)&ctx->pair_scratch, need));
             ctx->pair_scratch_bytes = need;
         }
         GL_ONCE_PER_DEVICE(ctx, \

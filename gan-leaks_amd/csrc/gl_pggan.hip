@@ -457,9 +457,9 @@ int gl_pggan_forward(gl_pggan *g, const float *z_dev, int64_t n, int steps, floa
         for (int k = 0; k < 2; ++k) { (void)hipFree(g->ws_rgb[k]); g->ws_rgb[k] = nullptr; }
         g->ws_z = nullptr;
         g->ws_imgs = 0; g->ws_act_elems = 0; g->ws_rgb_elems = 0;
-        GL_HIP(hipMalloc((void **)&g->ws_z, (size_t)z_rows * g->z_pad * 4));
-        for (int k = 0; k < 3; ++k) GL_HIP(hipMalloc((void **)&g->ws_buf[k], act_alloc * 4));
-        for (int k = 0; k < 2; ++k) GL_HIP(hipMalloc((void **)&g->ws_rgb[k], rgb_alloc * 4 + 64));
+        GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_z, (size_t)z_rows * g->z_pad * 4));
+        for (int k = 0; k < 3; ++k) GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_buf[k], act_alloc * 4));
+        for (int k = 0; k < 2; ++k) GL_HIP(gl_device_alloc(g->ctx, (void **)&g->ws_rgb[k], rgb_alloc * 4 + 64));
         g->ws_imgs = z_rows;
         g->ws_act_elems = act_alloc;
         g->ws_rgb_elems = rgb_alloc;

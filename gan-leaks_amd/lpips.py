@@ -60,6 +60,7 @@ class LpipsModel:
         check(self.ctx.lib.gl_lpips_create(self.ctx.handle, ctypes.byref(h)))
         self._handle = h
         self._loaded = False
+        self._warm = False            # shard.DeviceGroup: the calibration pass has run
         self._precision = 1
         # rows attack() builds for the nearest-neighbour search: 'fp16' = search rows (gl_feat_knn_h1: one fp16 MFMA per
         # product, 1.07 MB per 64x64 image), 'split' = hi + lo rows (gl_feat_knn: three MFMAs, 2.05 MB)
@@ -190,6 +191,37 @@ class LpipsModel:
         if role is not None:
             return FeatureBank(ctx, V, norms, n, K1, K - 3 * H * W, index_base, role, fmt, scale)
         return FeatureBank(ctx, V, norms, n, K, K - 3 * H * W, index_base)
+
+
+def features_sharded(model, images_u8, comm):
+    """query search rows with the VGG16 work split over the ranks of `comm` (the queries are replicated, so their features are
+    the one part of the path that does not shrink with the number of GPUs -- 64 ms of a 273 ms one-rank share of configs[2] at 8 GPUs):
+    rank r featurises images [r * per, (r + 1) * per), per = ceil(Q / nranks), straight into its block of the full row buffer; two in-place
+    all-gathers (rows, norms) on the context's stream give every rank all Q rows -- the same bits as featurising everything locally.
+    8-bit images only (lattice rows: the layout cannot differ between ranks).  `comm`: a `_lib.Comm` (or anything with rank, nranks,
+    allgather_rows(buf, bytes_per_rank))."""
+    ctx = model.ctx
+    shape = tuple(images_u8.shape)
+    if len(shape) != 4 or shape[1] != 3 or getattr(images_u8, "dtype", None) != np.uint8:
+        raise ValueError("features_sharded needs 8-bit images [n,3,H,W]")
+    Q, _, H, W = shape
+    K = int(ctx.lib.gl_lpips_feature_dim(H, W))
+    if K < 0:
+        raise ValueError("LPIPS path needs H and W to be multiples of 16, got %dx%d" % (H, W))
+    K1 = int(ctx.lib.gl_lpips_lattice_dim(H, W))
+    scale = float(ctx.lib.gl_lpips_lattice_scale(H, W))
+    world, rank = int(comm.nranks), int(comm.rank)
+    per = -(-Q // world)
+    V = ctx.empty((world * per, K1), np.float16)
+    norms = ctx.empty((world * per,), np.float32)
+    lo, hi = min(rank * per, Q), min((rank + 1) * per, Q)
+    if hi > lo:
+        mine = FeatureBank(ctx, V.view((hi - lo, K1), offset_bytes=lo * K1 * 2), norms.view((hi - lo,), offset_bytes=lo * 4), hi - lo, K1,
+                           K - 3 * H * W, 0, "query", "lattice", scale)
+        model.features(images_u8[lo:hi], role="query", fmt="lattice", out=mine)
+    comm.allgather_rows(V, per * K1 * 2)
+    comm.allgather_rows(norms, per * 4)
+    return FeatureBank(ctx, V, norms, Q, K1, K - 3 * H * W, 0, "query", "lattice", scale)
 
 
 _default = {"model": None, "factory": None}

@@ -242,9 +242,13 @@ class DeviceGroup:
                             from .lpips import model_for
                             self._models[rank] = model_for(ctx)
                     model = self._models[rank]
-                if self._queries[rank] is None or self._queries[rank][0] != qkey:
+                if model is not None and not model._warm:
+                    # the split path's calibration pass (first use of a model) is part of the fallible, collective-free setup
+                    model.features(np.zeros((1, 3, 32, 32), np.uint8), role="query")
+                    model._warm = True
+                if comms is None and (self._queries[rank] is None or self._queries[rank][0] != qkey):
+                    # no RCCL between the contexts: every context prepares all queries itself, which needs nobody else
                     self._queries[rank] = (qkey, prepare_queries(queries, distance, ctx, model), queries)   # (keeps `queries` alive: id() stays unique)
-                prepared = self._queries[rank][1]
                 ctx.sync()
             except BaseException as e:  # noqa: BLE001
                 fail(e, False)
@@ -254,6 +258,11 @@ class DeviceGroup:
             except threading.BrokenBarrierError:
                 return                                        # another rank failed in its setup; nothing was queued
             try:
+                if self._queries[rank] is None or self._queries[rank][0] != qkey:
+                    # with RCCL between the contexts the VGG16 features of the (replicated) queries are computed Q / world per rank and
+                    # all-gathered: a collective, hence behind the rendezvous
+                    self._queries[rank] = (qkey, prepare_queries(queries, distance, ctx, model, comm=comms[rank]), queries)
+                prepared = self._queries[rank][1]
                 results[rank] = attack(prepared, shard, distance=distance, batch_size=batch_size, ctx=ctx, reduce_fn=reduce_fn_for(rank, ctx),
                                        lpips=model, index_base=lo)
             except BaseException as e:  # noqa: BLE001

@@ -63,6 +63,10 @@ int gl_ctx_h3_saturations(gl_ctx *ctx, int64_t *out_count);
 /* device memory + copies (synchronous w.r.t. the context stream) */
 int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev);
 int gl_free(gl_ctx *ctx, void *dev);
+/* gl_free keeps blocks of >= 256 MiB in the context (an arena) and gl_malloc hands them out again for requests of the same size (up to 1/8
+ * smaller): the 153 GiB of query rows of a 256 x 256 attack cost 2-7 s to allocate and free per call otherwise.  gl_ctx_trim returns the kept
+ * blocks to the driver (the library does it itself when one of its allocations runs out of memory; gl_ctx_destroy does it too). */
+int gl_ctx_trim(gl_ctx *ctx);
 int gl_memcpy_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* `.to(device)`, fbb.py:135,141,145 */
 int gl_memcpy_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* `.item()`, fbb.py:88 */
 int gl_memset(gl_ctx *ctx, void *dev, int value, size_t bytes);
@@ -169,6 +173,11 @@ int gl_comm_rank(const gl_comm *comm, int *out_rank, int *out_nranks);
 /* keys_dev[q] = min over ranks of keys_dev[q], in place: ncclAllReduce(ncclMin, ncclUint64) queued on the context's stream -- behind the search
  * kernel that wrote the keys, ahead of gl_keys_unpack*; no host synchronisation.  Q x 8 bytes (80 KB at Q = 10^4): latency-bound. */
 int gl_allreduce_min_keys(gl_comm *comm, uint64_t *keys_dev, int64_t nq);
+/* recv_dev[r * bytes_per_rank ...] = rank r's send block, for every r: ncclAllGather on the context's stream (bytes as ncclUint8).  In place when
+ * send_dev == recv_dev + rank * bytes_per_rank.  Used to shard the one part of the path that is replicated otherwise, the VGG16 features of the
+ * queries (SURVEY.md 8e "shard it and all-gather if it shows up"): rank r featurises queries [r Q/N, (r+1) Q/N) and the search rows (1.02 MB
+ * each at 64 x 64) are gathered; measured on one-rank shares, configs[2] projects to 5.8 x at 8 GPUs with replicated query features. */
+int gl_allgather_rows(gl_comm *comm, const void *send_dev, void *recv_dev, int64_t bytes_per_rank);
 int gl_comm_group_start(void);                                                                 /* ncclGroupStart */
 int gl_comm_group_end(void);                                                                   /* ncclGroupEnd */
 

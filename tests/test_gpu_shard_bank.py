@@ -139,3 +139,55 @@ def test_fbb_ngpu_flag_matches_single_device(tmp_path, monkeypatch, synth, golde
         lpips.set_default_factory(None)
     assert fbb.shard_devices(fbb.parse_arguments(base + ["--ngpu", "4"])) == [0, 1, 2, 3]
     assert fbb.shard_devices(fbb.parse_arguments(base)) is None
+
+
+def test_sharded_query_features_equal_replicated_ones(synth, golden_dir):
+    """lpips.features_sharded: rank r featurises queries [r per, (r + 1) per) into its block, all-gathers rows and norms.  One GPU cannot run
+    several RCCL ranks, so the gather is played by a stand-in that fills the other ranks' blocks the way they would (each from its own
+    slice); what is checked is the block arithmetic -- ragged last rank, ranks without queries -- and that the result is bit for bit what
+    every rank gets by featurising all queries itself.  The real collective runs on a one-rank communicator (in-place copy)."""
+    import ganleaks_amd as gl
+    from ganleaks_amd import lpips as lp
+    from ganleaks_amd._lib import Comm
+    from ganleaks_amd.attack import prepare_queries
+    ctx = gl.Context.get()
+    model = _lpips_factory(synth, golden_dir)(ctx)
+    q = synth.lowpass_u8_images(77, 43, 32)
+    full = model.features(q, role="query")
+    K1 = full.K
+
+    class Stand_in:
+        def __init__(self, rank, nranks):
+            self.rank, self.nranks, self.calls = rank, nranks, 0
+
+        def allgather_rows(self, buf, bytes_per_rank):
+            # the other ranks' blocks, as they would have produced them; rows gathered first, norms second
+            per = -(-len(q) // self.nranks)
+            for r in range(self.nranks):
+                lo, hi = min(r * per, len(q)), min((r + 1) * per, len(q))
+                if r == self.rank or hi <= lo:
+                    continue
+                other = model.features(q[lo:hi], role="query")
+                src = other.V if self.calls == 0 else other.norms
+                host = src.numpy()[:hi - lo]
+                ctx.to_device(host)          # (exercise the upload path)
+                from ganleaks_amd._lib import check
+                import ctypes
+                check(ctx.lib.gl_memcpy_h2d(ctx.handle, ctypes.c_void_p(buf.ptr + r * bytes_per_rank), host.ctypes.data_as(ctypes.c_void_p), host.nbytes))
+            self.calls += 1
+            return buf
+
+    for world in (2, 3, 8):
+        for rank in (0, world - 1):
+            fb = lp.features_sharded(model, q, Stand_in(rank, world))
+            assert fb.n == len(q) and fb.K == K1 and fb.fmt == "lattice" and fb.role == "query"
+            assert np.array_equal(fb.V.numpy()[:len(q)], full.V.numpy()) and np.array_equal(fb.norms.numpy()[:len(q)], full.norms.numpy()), (world, rank)
+    # more ranks than queries would leave ranks empty: prepare_queries keeps such small sets replicated
+    one = Comm(ctx, Comm.unique_id(), 0, 1)
+    fb1 = lp.features_sharded(model, q, one)                       # the real ncclAllGather, one rank: in-place
+    ctx.sync()
+    assert np.array_equal(fb1.V.numpy(), full.V.numpy()) and np.array_equal(fb1.norms.numpy(), full.norms.numpy())
+    assert prepare_queries(q, "l2-lpips", ctx, model, comm=one).V.shape[0] == len(q)     # one rank: the replicated form
+    one.destroy()
+    with pytest.raises(ValueError):
+        lp.features_sharded(model, q.astype(np.float32), Stand_in(0, 2))
