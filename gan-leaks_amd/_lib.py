@@ -52,6 +52,7 @@ SIGNATURES = {
     "gl_malloc": (_i, [_p, _sz, _pp]),
     "gl_free": (_i, [_p, _p]),
     "gl_ctx_trim": (_i, [_p]),
+    "gl_mem_info": (_i, [_p, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "gl_memcpy_h2d": (_i, [_p, _p, _p, _sz]),
     "gl_memcpy_d2h": (_i, [_p, _p, _p, _sz]),
     "gl_memset": (_i, [_p, _p, _i, _sz]),
@@ -225,6 +226,12 @@ class Context:
 
     def sync(self):
         check(self.lib.gl_ctx_sync(self.handle))
+
+    def mem_info(self):
+        """(available, total) bytes of the context's GPU; available = free + what the arena keeps (gl_mem_info)"""
+        a, t = _sz(0), _sz(0)
+        check(self.lib.gl_mem_info(self.handle, ctypes.byref(a), ctypes.byref(t)))
+        return int(a.value), int(t.value)
 
     def trim(self):
         """return the large device blocks the context keeps for reuse (gl_free's arena, include/ganleaks.h) to the driver"""

@@ -172,15 +172,22 @@ def _budget_bytes():
     return int(float(os.environ.get("GANLEAKS_CHUNK_GB", "64")) * (1 << 30))
 
 
-def _query_budget_bytes(chunk_bytes):
-    """HBM the prepared QUERY rows of a streamed l2-lpips attack may occupy next to one bank chunk ($GANLEAKS_QUERY_GB; default: 192 GiB of an
-    MI355X's 288 GB when the bank chunk has its default 64 GiB, the same as the chunk otherwise).  Query rows that fit stay resident for
-    the whole bank stream -- 10 000 search rows of 256 x 256 images are 160 GiB -- so the bank is generated and featurised once; rows that
-    do not fit go in slices, each against the whole (regenerated) bank stream."""
+def _query_budget_bytes(chunk_bytes, ctx=None):
+    """HBM the prepared QUERY rows of a streamed l2-lpips attack may occupy next to one bank chunk: $GANLEAKS_QUERY_GB if set, else what the
+    device has available right now (gl_mem_info) minus the bank chunk and 12 GiB for the workspaces of the generator and of VGG16 (two
+    activation buffers of up to 3 GiB each), the search scratch and the allocator's slack -- 191 GiB on an idle 288 GB MI355X with the
+    default 64 GiB chunk.  Query rows that fit stay resident for the whole bank stream -- 10 000 search rows of 256 x 256 images are
+    153 GiB -- so the bank is generated and featurised once; rows that do not fit go in slices, each against the whole (regenerated) bank
+    stream."""
     import os
     if "GANLEAKS_QUERY_GB" in os.environ:
         return int(float(os.environ["GANLEAKS_QUERY_GB"]) * (1 << 30))
-    return 192 * (1 << 30) if chunk_bytes == 64 * (1 << 30) else chunk_bytes
+    if chunk_bytes != 64 * (1 << 30):
+        return chunk_bytes                 # a caller who set its own chunk budget gets the same budget for the query rows
+    if ctx is None:
+        return 192 * (1 << 30)
+    available, _ = ctx.mem_info()
+    return max(available - int(chunk_bytes) - 12 * (1 << 30), min(int(chunk_bytes), available // 4))
 
 
 def float_path(value=None):
@@ -268,7 +275,7 @@ def _attack_streamed(queries, bank, n_rows, distance, ctx, reduce_fn, model, chu
             # query rows that would not fit the budget either (256 x 256 images: 17 MB per search row) go in slices, each against
             # the whole bank stream -- the bank's features are then recomputed once per slice
             per_q = _feature_row_bytes(ctx, model, queries)
-            q_step = max(1, int(_query_budget_bytes(chunk_bytes) // per_q))
+            q_step = max(1, int(_query_budget_bytes(chunk_bytes, ctx) // per_q))
             if len(queries) > q_step:
                 parts = [_attack_streamed(queries[a:a + q_step], bank, n_rows, distance, ctx, reduce_fn, model, chunk_bytes, fpath, index_base)
                          for a in range(0, len(queries), q_step)]

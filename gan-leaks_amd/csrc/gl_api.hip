@@ -218,6 +218,22 @@ int gl_ctx_trim(gl_ctx *ctx)
     return GL_OK;
 }
 
+int gl_mem_info(gl_ctx *ctx, size_t *out_available, size_t *out_total)
+{
+    gl_make_current(ctx);
+    GL_REQUIRE(ctx && out_available && out_total, "gl_mem_info: NULL argument");
+    GL_HIP(hipSetDevice(ctx->device));
+    size_t free_b = 0, total_b = 0;
+    GL_HIP(hipMemGetInfo(&free_b, &total_b));
+    {
+        std::lock_guard<std::mutex> lk(*ctx->arena_mu);
+        for (auto &b : ctx->arena_free) free_b += b.first;
+    }
+    *out_available = free_b;
+    *out_total = total_b;
+    return GL_OK;
+}
+
 int gl_malloc(gl_ctx *ctx, size_t bytes, void **out_dev)
 {
     gl_make_current(ctx);

@@ -45,7 +45,16 @@ constexpr int HBK_BYTES = 128;          // one K slice of 32 channels: 64 B hi +
 // headline step went from 192 to 210-222 ms.  A class-pure tile of 256 rows spans 64 to 256 images instead of 16, and the re-use of an input
 // pixel by its 4 taps x 4 phases, which a raster tile gets from its own L2 footprint, is gone.  Not kept.
 // UP: the input is read through nearest-neighbour x2 upsampling (p.up; a template parameter so that the common form does not carry its registers)
-template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false>
+// T4 (round 3; the 256 x 256 tile on a 4 x 4 input grid: DCGAN's 4 x 4 -> 8 x 8 layer, VGG16 conv5_x and PGGAN's first block at 64 x 64):
+//   a tile holds the 16 positions of 16 images either way, but its rows are ordered so that every 16-row MFMA fragment is ONE position of
+//   the 16 images, and the fragments are dealt to the 4 position-waves as a Latin square -- wave wp, fragment j holds position
+//   (y, x) = (j, (j + wp) mod 4): one of every row and one of every column per wave.  A tap that falls outside the image for a position
+//   does so for the whole fragment (all-zero operand), so its 3 x TC MFMAs and its two fragment reads are skipped: 18.75 % of the
+//   layer's MFMAs for ConvTranspose k4 s2 p1 (the ideal, 23.4 %, would need the corner fragment on every wave), ~27 % for a 3 x 3 p1
+//   convolution; every wave skips (nearly) the same number per slice, so the SIMDs stay in step.  Same images per tile as the raster
+//   order, hence the same L2 footprint (the border-sorted order above lost exactly that).  Adding a zero product changes no bit: outputs are
+//   identical to the raster form's (tests/test_gpu_dcgan.py).
+template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false, bool T4 = false>
 __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const GlGatherConv p, int m_tiles, int n_tiles, int phases)
 {
 #if __HIP_DEVICE_COMPILE__
@@ -53,6 +62,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
     constexpr int W_BYTES = HTC * HBK_BYTES, X_BYTES = HTP * HBK_BYTES, BUF = W_BYTES + X_BYTES;
     constexpr int NW = WC * WP;
     constexpr int PW = (HTC / 8) / NW, PX = (HTP / 8) / NW;   // 1-KiB staging pieces per wave and slice
+    static_assert(!T4 || (HTP == 256 && TP == 4 && WP == 4 && PX == 4 && !UP && !FUSE_TAIL), "T4: the 256-position tile with 4 position-waves of 4 fragments");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][W | X]
 
     const unsigned inner = (unsigned)phases * (unsigned)n_tiles;
@@ -93,11 +103,13 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         w_voff0 = ((unsigned)(c0 + r) * (unsigned)K) * 4u + (unsigned)(slot ^ rsub) * 16u;
     }
     const unsigned w_step = 8u * (unsigned)K * 4u, x_step = 8u * (unsigned)p.Cin * 4u;
+    // T4: tile row r = fragment (r >> 4) x image (r & 15); fragment f = 4 wp + j holds position 4 j + ((j + wp) & 3) of the 4 x 4 grid
+    auto t4_pos = [](int r) -> int { const int f = r >> 4, wpp = f >> 2, j = f & 3; return (r & 15) * 16 + 4 * j + ((j + wpp) & 3); };
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
         const int r = (wave * PX + i) * 8 + rsub;
         const int chunk = slot ^ (r & 7);
-        const int64_t pos = m0 + r;
+        const int64_t pos = m0 + (T4 ? t4_pos(r) : r);
         if constexpr (UP) { x_img[i] = 0; x_yx[i] = 0; }
         if (pos < p.positions) {
             const int64_t img = pos / HW;
@@ -107,7 +119,9 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
                 const int yy = y + (int)((tdy >> (2 * t)) & 3u) - 1, xx = x + (int)((tdx >> (2 * t)) & 3u) - 1;
                 if ((yy >= 0) & (yy < p.H) & (xx >= 0) & (xx < p.W)) x_mask2[i >> 1] |= 1u << (t + (i & 1) * 16);
             }
-            if (i == 0) x_voff0 = (unsigned)pos * (unsigned)p.Cin * 4u + (unsigned)chunk * 16u;      // pieces are 8 positions apart
+            // raster: pieces are 8 positions apart; T4: the same lane of piece i is (t4_pos(8 i + r0) - t4_pos(r0)) positions further, a
+            // wave-uniform distance as well (the row inside the piece is the image, r & 7 = rsub for every piece)
+            if (i == 0 || T4) { if (i == 0) x_voff0 = (unsigned)pos * (unsigned)p.Cin * 4u + (unsigned)chunk * 16u; }
             if constexpr (UP) { x_img[i] = (int)(img * Hs * Ws); x_yx[i] = y | (x << 16); }
         }
     }
@@ -126,7 +140,9 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 const unsigned voff = (x_mask_of(i) & tapbit) ? x_voff0 : kOOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff + (unsigned)i * x_step, 0, 0);
+                unsigned piece = (unsigned)i * x_step;
+                if constexpr (T4) piece = (unsigned)(t4_pos((wave * PX + i) * 8) - t4_pos(wave * PX * 8)) * (unsigned)p.Cin * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(buf + W_BYTES + (wave * PX + i) * 1024), 16, voff, soff + piece, 0, 0);
             }
         } else {
             const unsigned soff = (unsigned)cc * 128u;
@@ -148,10 +164,20 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
         for (int j = 0; j < TP; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
     const int frow0 = lane0 & 15, fk0 = lane0 >> 4;
-    auto compute = [&](const char *cur) {
+    auto compute = [&](const char *cur, int kt) {
         const char *lw = cur + (wc * 16 * TC) * HBK_BYTES;
         const char *lx = cur + W_BYTES + (wp_ * 16 * TP) * HBK_BYTES;
         v8h w_hi[TC], w_lo[TC], x_hi[TP], x_lo[TP];
+        unsigned skip = 0;                                 // T4: bit j = fragment j of this wave lies outside the image for this slice's tap
+        if constexpr (T4) {
+            const int tap = kt % p.ntaps;
+            const int dy = (int)((tdy >> (2 * tap)) & 3u) - 1, dx = (int)((tdx >> (2 * tap)) & 3u) - 1;
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int yy = j + dy, xx = ((j + wp_) & 3) + dx;
+                skip |= ((yy < 0) | (yy > 3) | (xx < 0) | (xx > 3)) ? 1u << j : 0u;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             const int r = i * 16 + frow0;
@@ -164,20 +190,34 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
             x_hi[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + ((fk0 ^ (r & 7)) << 4));
             x_lo[j] = *reinterpret_cast<const v8h *>(lx + r * HBK_BYTES + (((4 + fk0) ^ (r & 7)) << 4));
         }
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
+        if constexpr (T4) {
+            // fragment-major, so that a skipped fragment is one wave-uniform branch around 3 TC MFMAs (the zero products it drops change no bit)
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[i], x_hi[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_lo[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_hi[j], acc[i][j], 0, 0, 0);
+                if ((skip >> j) & 1u) continue;
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[i], x_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_lo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_hi[j], acc[i][j], 0, 0, 0);
+                }
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TP; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[i], x_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_lo[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], x_hi[j], acc[i][j], 0, 0, 0);
+                }
+        }
     };
     stage(0, smem);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
         if (kt + 1 < nk) stage(kt + 1, smem + ((kt + 1) & 1) * BUF);
-        compute(smem + (kt & 1) * BUF);
+        compute(smem + (kt & 1) * BUF, kt);
     }
 
     // ---- epilogue.  C tile (16 x 16): column (position) = lane & 15, row (channel) = 4 * (lane >> 4) + reg.
@@ -190,7 +230,7 @@ __global__ void __launch_bounds__(64 * WC * WP, 2) gather_conv_h3_kernel(const G
     const int tid = tid_again, lane = tid_again & 63, frow = tid_again & 15, fk = (tid_again & 63) >> 4;
     int *orow = reinterpret_cast<int *>(smem);
     if (tid < HTP) {
-        const int64_t pos = m0 + tid;
+        const int64_t pos = m0 + (T4 ? t4_pos(tid) : tid);
         int o = -1;
         if (pos < p.positions) {
             const int64_t img = pos / HW;
@@ -300,18 +340,23 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float *__restrict
 
 }  // namespace
 
-template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false>
+template <int WC, int WP, int TC = 4, int TP = 4, bool FUSE_TAIL = false, bool UP = false, bool T4 = false>
 static int launch_h3(gl_ctx *ctx, const GlGatherConv &p, int phases)
 {
-    if constexpr (!UP && !FUSE_TAIL) {
+    if constexpr (!UP && !FUSE_TAIL && !T4) {
         if (p.up) return launch_h3<WC, WP, TC, TP, FUSE_TAIL, true>(ctx, p, phases);
+    }
+    if constexpr (WC == 2 && WP == 4 && TC == 8 && TP == 4 && !UP && !FUSE_TAIL && !T4) {
+        // a 4 x 4 input grid: the fragment-per-position row order, which skips the MFMAs of taps that fall outside the image
+        const bool plain = !p.up && !p.tail_w && !p.tap_V && !p.rgb_out && p.pixnorm_act == 0.0f && !p.planar;
+        if (plain && p.H == 4 && p.W == 4 && gl_tuning_int("GL_H3_T4", 1)) return launch_h3<WC, WP, TC, TP, false, false, true>(ctx, p, phases);
     }
     constexpr int HTC = 16 * TC * WC, HTP = 16 * TP * WP;
     const int64_t m_tiles = gl_ceil_div(p.positions, HTP);
     const int n_tiles = (int)gl_ceil_div(p.cols, HTC);       // weight rows are padded to cols_pad >= n_tiles * HTC
     GL_REQUIRE(m_tiles * n_tiles * phases < (1ll << 31), "gather_conv_h3: grid too large");
     constexpr int lds = 2 * (HTC + HTP) * HBK_BYTES;
-    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP, FUSE_TAIL, UP>;
+    auto kern = gather_conv_h3_kernel<WC, WP, TC, TP, FUSE_TAIL, UP, T4>;
     GL_ONCE_PER_DEVICE(ctx, \
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);

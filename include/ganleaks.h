@@ -67,6 +67,9 @@ int gl_free(gl_ctx *ctx, void *dev);
  * smaller): the 153 GiB of query rows of a 256 x 256 attack cost 2-7 s to allocate and free per call otherwise.  gl_ctx_trim returns the kept
  * blocks to the driver (the library does it itself when one of its allocations runs out of memory; gl_ctx_destroy does it too). */
 int gl_ctx_trim(gl_ctx *ctx);
+/* device memory of the context's GPU: *out_available = bytes a gl_malloc could get right now (hipMemGetInfo's free bytes + the blocks the arena
+ * keeps), *out_total = the device's memory.  attack() sizes the resident query rows of a streamed search from it. */
+int gl_mem_info(gl_ctx *ctx, size_t *out_available, size_t *out_total);
 int gl_memcpy_h2d(gl_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);   /* `.to(device)`, fbb.py:135,141,145 */
 int gl_memcpy_d2h(gl_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);   /* `.item()`, fbb.py:88 */
 int gl_memset(gl_ctx *ctx, void *dev, int value, size_t bytes);

@@ -5,6 +5,7 @@ the tuning build (libganleaks_hip_tuning.so, -DGL_TUNING), which is loaded in a 
   int8 L2 search    : round-1 kernel (variant 0) == pipelined kernel (variant 1; what the shipped library runs) -- exact integers
   fp16 LPIPS search : persistent cluster kernel (3; shipped) == persistent kernel without clusters (5; what a device with fewer than
                       256 CUs gets): the same K segments and totals, so the same bits on any device
+  convolutions      : the 4 x 4-grid tile order that skips the MFMAs of outside taps (GL_H3_T4=1; shipped) == the raster order (0)
 """
 import json
 import os
@@ -58,6 +59,23 @@ d3 = (fk[3] >> np.uint64(32)).astype(np.uint32).view(np.float32)
 d1 = (fk[1] >> np.uint64(32)).astype(np.uint32).view(np.float32)
 out["feat_unsegmented_rel_diff"] = float(np.max(np.abs(d3 - d1) / np.maximum(d3, 1e-30)))
 out["feat_idx_equal_unsegmented"] = bool(np.array_equal(fk[3] & np.uint64(0xFFFFFFFF), fk[1] & np.uint64(0xFFFFFFFF)))
+# the 4 x 4-grid tile order of gather_conv_h3 (T4: one position of 16 images per MFMA fragment, fragments of outside taps skipped) against the
+# raster order: DCGAN's first strided layer and VGG16's conv5_x take it when the pass is large enough for the 256 x 256 tile
+from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+from ganleaks_amd.lpips import LpipsModel
+g = Generator(100, 3, 64, ctx)
+g.load_state_dict(gl.synth.dcgan_state_dict(1234))
+z = gl.synth.latent(11, 1100)                       # 1100 images: a ragged last tile of 12 images
+lin = np.load(os.path.join(%(root)r, "tests", "golden", "lpips_lin_v0.1.npz"))
+m = LpipsModel(ctx).load_state_dicts(gl.synth.vgg16_state_dict(7), {"lin%%d" %% i: lin["lin%%d" %% i] for i in range(5)})
+imgs = rng.integers(0, 256, size=(2100, 3, 64, 64), dtype=np.uint8)
+res = {}
+for v in (1, 0):
+    os.environ["GL_H3_T4"] = str(v)
+    f32, u8 = g.forward_device(z, True, True)
+    fb = m.features(imgs, role="bank")
+    res[v] = (f32.numpy().copy(), u8.numpy().copy(), fb.V.numpy().copy(), fb.norms.numpy().copy())
+out["t4_equals_raster"] = [bool(np.array_equal(a, b)) for a, b in zip(res[1], res[0])]
 print("RESULT " + json.dumps(out))
 '''
 
@@ -74,3 +92,4 @@ def test_shipped_kernels_match_their_plain_siblings_bit_for_bit():
     assert out["l2_equal"] == [True, True, True], out
     assert out["feat_cluster_equals_plain_persistent"] is True, out
     assert out["feat_unsegmented_rel_diff"] < 1e-4 and out["feat_idx_equal_unsegmented"], out
+    assert out["t4_equals_raster"] == [True, True, True, True], out

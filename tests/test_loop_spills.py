@@ -15,4 +15,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_no_spills_inside_the_k_loops():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_loop_spills.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("0 scratch instructions inside the K loop") >= 11
+    assert r.stdout.count("0 scratch instructions inside the K loop") >= 12
+    # the hand-placed fragment reads of gl_pair256.h: nothing touches a destination register between its ds_read and the wait that retires it
+    assert r.stdout.count(", 0 instructions touch a fragment register still in flight") == 3, r.stdout

@@ -69,7 +69,7 @@ def main():
         ok = bool(np.array_equal(i[:len(planted)], np.minimum(planted, n_eff - 1))) if planted.max() < n_eff else None
         row_bytes = 2 * K1
         from ganleaks_amd.attack import _budget_bytes, _query_budget_bytes
-        slices = int(np.ceil(Q * row_bytes / _query_budget_bytes(_budget_bytes())))
+        slices = int(np.ceil(Q * row_bytes / _query_budget_bytes(_budget_bytes(), ctx)))
         emit(config="configs[3] one rank of 8: PGGAN-256, %d queries x %d-sample shard, 0.2*LPIPS+L2 at 256x256, streamed" % (Q, N),
              seconds=round(dt, 2), query_images_per_s_this_rank=round(Q / dt, 2), planted_found=ok,
              feat_knn={"launches": int(knn_n), "total_s": round(knn_ms / 1e3, 2), "alg_tflops": round(2.0 * Q * n_eff * K_alg / (knn_ms * 1e-3) / 1e12, 1),
