@@ -124,6 +124,7 @@ SIGNATURES = {
     "gl_rows_knn_split": (_i, [_p, _p, _p, _p, _i64, _i64, _p, _p, _p, _i64, _i64, _p]),
     "gl_lpips_search_dim": (_i64, [_i, _i]),
     "gl_lpips_lattice_dim": (_i64, [_i, _i]),
+    "gl_lpips_search_rows_capacity": (_i64, [_i64, _i64]),
     "gl_lpips_lattice_scale": (ctypes.c_float, [_i, _i]),
     "gl_lpips_lattice_features_u8": (_i, [_p, _p, _i64, _i, _i, _p, _p]),
     "gl_lpips_search_features_u8": (_i, [_p, _p, _i64, _i, _i, _i, _p, _p]),

@@ -62,15 +62,34 @@ struct GlGatherConv {
     float *rgb_out;             // nullptr = off
     int rgb_n;
     float rgb_inv_act;
-    char *tap_V;                // nullptr = off
+    char *tap_V;                // nullptr = off; base of the row buffer
     const float *tap_coef;
-    int64_t tap_ldv, tap_off;
+    int64_t tap_ldv, tap_off;   // tap_ldv: bytes per row, or (fp16 rows only) -(cells per row) for the K-blocked layout, see gl_vrow_elem
+    int64_t tap_row0;           // buffer row of the pass's image 0
     int tap_fmt;
     char *tap_pool;
     float tap_scale, tap_eps;   // V = v * (tap_scale / (sqrt(sum v^2) + tap_eps)) * coef
 };
 
+// fp16 search rows (LPIPS feature rows for the nearest-neighbour search) come in two layouts, chosen by the row length alone so that writers and
+// the search agree without a flag in the ABI (gl_vrow_blocked):
+//   row-major   [row][K] halves                                   -- rows shorter than 2 MiB (images up to 64 x 64 ... 80 x 80)
+//   K-blocked   [row / 256][K / 64][row % 256][64 halves]          -- longer rows (96 x 96: 2.3 MiB, 128 x 128: 4 MiB, 256 x 256: 16 MiB per row)
+// The search kernel reads the same 128-byte K slice of the 512 rows of a tile together.  With 16 MiB rows those are 512 different 2 MiB pages
+// at every slice: measured on the persistent kernel at 256 x 256 (round 3, tools/pmc_tlb_search.sh) 44 % of the UTCL1 translations miss and the
+// UTCL2 is busy 72 % of the time, against 0.013 % / 3 % at 64 x 64, and the kernel runs at 0.49 of the fp16 peak per busy cluster instead of
+// 0.58.  K-blocked, a tile's slice is ONE contiguous 32 KiB piece per operand.  A buffer of n rows holds ceil(n / 256) * 256 rows.
+static inline bool gl_vrow_blocked(int64_t K1_halves) { return K1_halves * 2 >= (2ll << 20); }
+static inline int64_t gl_vrow_capacity(int64_t n, int64_t K1_halves) { return gl_vrow_blocked(K1_halves) ? (n + 255) / 256 * 256 : n; }
+
 #if defined(__HIPCC__)
+// address of half k of fp16 search row `row`: ldv >= 0: row-major with ldv bytes per row; ldv < 0: K-blocked with -ldv cells of 64 halves per row
+__device__ __forceinline__ char *gl_vrow_elem(char *V, int64_t ldv, int64_t row, int64_t k)
+{
+    if (ldv >= 0) return V + row * ldv + k * 2;
+    return V + ((row >> 8) * (-ldv) + (k >> 6)) * 32768 + (row & 255) * 128 + (k & 63) * 2;
+}
+
 // (v * inv) * coef with both products rounded to fp32 and MATERIALISED: without the empty asm hipcc is free to fold a product into the
 // conversion or subtraction that follows it (v_fma_mix*, fma contraction), differently in different kernels, and the fused and the
 // stand-alone tap would stop agreeing bit for bit.

@@ -133,11 +133,10 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
                         ol[r] = (_Float16)__fsub_rn(t, (float)oh[r]);
                     }
                     const int64_t k = p.tap_off + (int64_t)pin[j] * p.cols + ch;
-                    char *row = p.tap_V + (int64_t)img[j] * p.tap_ldv;
                     if (p.tap_fmt) {
-                        *reinterpret_cast<v4h *>(row + k * 2) = oh;
+                        *reinterpret_cast<v4h *>(gl_vrow_elem(p.tap_V, p.tap_ldv, p.tap_row0 + img[j], k)) = oh;
                     } else {
-                        char *dst = row + (k >> 5) * 128 + (k & 31) * 2;
+                        char *dst = p.tap_V + (p.tap_row0 + img[j]) * p.tap_ldv + (k >> 5) * 128 + (k & 31) * 2;
                         *reinterpret_cast<v4h *>(dst) = oh;
                         *reinterpret_cast<v4h *>(dst + 64) = ol;
                     }

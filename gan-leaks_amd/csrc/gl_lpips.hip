@@ -86,22 +86,22 @@ __device__ __forceinline__ void split_store2(char *row, int64_t k, float a, floa
 
 // "search" rows (H1 = true): one fp16 per value (V * 2^14 rounded once), K contiguous -- the operand of feat_knn_h1_kernel
 template <bool H1>
-__device__ __forceinline__ void v_store2(char *row, int64_t k, float a, float b)
+__device__ __forceinline__ void v_store2(char *V, int64_t ldv, int64_t row, int64_t k, float a, float b)
 {
     if constexpr (H1) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2 h;
         h[0] = (_Float16)a; h[1] = (_Float16)b;
-        *reinterpret_cast<h2 *>(row + k * 2) = h;
+        *reinterpret_cast<h2 *>(gl_vrow_elem(V, ldv, row, k)) = h;
     } else {
-        split_store2(row, k, a, b);
+        split_store2(V + row * ldv, k, a, b);
     }
 }
 
 // one wave per position: f / (sqrt(sum_c f^2) + 1e-10) * coef_c  ->  V[img][off + pos*C + c]   (C % 64 == 0), split layout
 template <bool H1>
 __global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict__ f, int64_t n, int HW, int C, const float *__restrict__ coef,
-                                                        char *__restrict__ V, int64_t ldv_bytes, int64_t off)
+                                                        char *__restrict__ V, int64_t ldv_bytes, int64_t off, int64_t row0)
 {
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -115,11 +115,10 @@ __global__ void __launch_bounds__(256) lpips_tap_kernel(const float *__restrict_
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         const float inv = kVScale / (sqrtf(ss) + 1e-10f);        // eps outside the sqrt (util.py:72-73)
         const int64_t im = pos / HW;
-        char *row = V + im * ldv_bytes;
         const int64_t k0 = off + (pos - im * HW) * C;
         for (int c = 2 * lane; c < C; c += 128) {
             const float2 t = *reinterpret_cast<const float2 *>(src + c);
-            v_store2<H1>(row, k0 + c, t.x * inv * coef[c], t.y * inv * coef[c + 1]);
+            v_store2<H1>(V, ldv_bytes, row0 + im, k0 + c, t.x * inv * coef[c], t.y * inv * coef[c + 1]);
         }
     }
 }
@@ -148,7 +147,7 @@ __global__ void __launch_bounds__(256) image_part_kernel(const T *__restrict__ i
 // (8-bit images take only 256 values, so rounding x to ONE half gives a systematic ~1e-4 error in the L2 term; the LPIPS values do not)
 template <typename T>
 __global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict__ img, int64_t n, int64_t D, int64_t Dp, float inv_sqrt_d, char *__restrict__ V,
-                                                            int64_t ldv_bytes, int64_t off, int lo_seg, int pad)
+                                                            int64_t ldv_bytes, int64_t off, int lo_seg, int pad, int64_t row0)
 {
     __shared__ float lut[256];
     lut[threadIdx.x] = (float)(2.0 * ((double)threadIdx.x / 255.0) - 1.0);
@@ -162,48 +161,48 @@ __global__ void __launch_bounds__(256) image_part_h1_kernel(const T *__restrict_
         const float v = k < D ? load_pixel(img + im * D + k, lut) * sc : 0.0f;
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);
-        _Float16 *row = reinterpret_cast<_Float16 *>(V + im * ldv_bytes) + off;
-        row[k] = hi;
-        row[hi2_seg * Dp + k] = hi;
-        row[lo_seg * Dp + k] = lo;
-        if (k < pad) row[3 * Dp + k] = (_Float16)0.0f;       // the zero tail of a padded row (lp_search_pad)
+        auto at = [&](int64_t kk) -> _Float16 & { return *reinterpret_cast<_Float16 *>(gl_vrow_elem(V, ldv_bytes, row0 + im, off + kk)); };
+        at(k) = hi;
+        at(hi2_seg * Dp + k) = hi;
+        at(lo_seg * Dp + k) = lo;
+        if (k < pad) at(3 * Dp + k) = (_Float16)0.0f;       // the zero tail of a padded row (lp_search_pad)
     }
 }
 
 // image part of a lattice search row: (2 code - 255) * 2^e, exact in fp16; zero padded to Dp + pad
 __global__ void __launch_bounds__(256) image_part_lattice_kernel(const uint8_t *__restrict__ img, int64_t n, int64_t D, int64_t Dp_pad, float two_e,
-                                                                 char *__restrict__ V, int64_t ldv_bytes, int64_t off)
+                                                                 char *__restrict__ V, int64_t ldv_bytes, int64_t off, int64_t row0)
 {
     const int64_t total = n * Dp_pad;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t im = i / Dp_pad;
         const int64_t k = i - im * Dp_pad;
         const float v = k < D ? (float)(2 * (int)img[im * D + k] - 255) * two_e : 0.0f;
-        reinterpret_cast<_Float16 *>(V + im * ldv_bytes)[off + k] = (_Float16)v;
+        *reinterpret_cast<_Float16 *>(gl_vrow_elem(V, ldv_bytes, row0 + im, off + k)) = (_Float16)v;
     }
 }
 
 // |row|^2 of a search row (unscaled): sum over the LPIPS halves of h^2 + sum over the image part of (hi + lo)^2
 constexpr int kNormSeg = 32768;          // halves of a row per workgroup
 __global__ void __launch_bounds__(256) row_sqnorm_h1_part_kernel(const char *__restrict__ V, int64_t ldv_bytes, int64_t K_lp, int64_t Dp, int lo_seg, int nseg,
-                                                                  double *__restrict__ part)
+                                                                  double *__restrict__ part, int64_t row0)
 {
     // grid (segment, row): a 17 MB row of a 256 x 256 image is summed by 262 workgroups, not one (passes of that size have 128 rows); the
     // segmentation depends on the row length only, so a row's norm does not depend on the pass it is computed in
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     __shared__ double red[256];
     const int64_t r = blockIdx.y;
-    const _Float16 *row = reinterpret_cast<const _Float16 *>(V + r * ldv_bytes);
+    char *Vm = const_cast<char *>(V);
     const int64_t k0 = (int64_t)blockIdx.x * kNormSeg;
     const int64_t kend = k0 + kNormSeg < K_lp + Dp ? k0 + kNormSeg : K_lp + Dp;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int64_t k = k0 + (int64_t)threadIdx.x * 8; k < kend; k += 256 * 8) {
-        const h8 h = *reinterpret_cast<const h8 *>(row + k);
+        const h8 h = *reinterpret_cast<const h8 *>(gl_vrow_elem(Vm, ldv_bytes, row0 + r, k));
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (float)h[j];
         if (lo_seg > 0 && k >= K_lp) {
-            const h8 l = *reinterpret_cast<const h8 *>(row + k + lo_seg * Dp);
+            const h8 l = *reinterpret_cast<const h8 *>(gl_vrow_elem(Vm, ldv_bytes, row0 + r, k + lo_seg * Dp));
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)l[j];
         }
@@ -482,7 +481,7 @@ __device__ __forceinline__ float tap_sumsq_across(float s)
 // 512 / C positions per pass with 2 KiB of contiguous reads and C * 2 (or 4) bytes of contiguous writes per position.
 template <bool H1, int C>
 __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__restrict__ f, int64_t n, int HW, const float *__restrict__ coef,
-                                                              char *__restrict__ V, int64_t ldv_bytes, int64_t off, float tap_eps)
+                                                              char *__restrict__ V, int64_t ldv_bytes, int64_t off, float tap_eps, int64_t row0)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr int G = C / 8;            // lanes per position
@@ -512,7 +511,6 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
         if (!live) continue;
         const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), tap_eps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
         const int64_t im = pos / HW;
-        char *row = V + im * ldv_bytes;
         const int64_t k = off + (pos - im * HW) * C + cb * 8;
         h8 oh, ol;
 #pragma unroll
@@ -522,9 +520,9 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
             ol[j] = (_Float16)__fsub_rn(t, (float)oh[j]);
         }
         if constexpr (H1) {
-            *reinterpret_cast<h8 *>(row + k * 2) = oh;
+            *reinterpret_cast<h8 *>(gl_vrow_elem(V, ldv_bytes, row0 + im, k)) = oh;
         } else {
-            char *dst = row + split_off(k);
+            char *dst = V + (row0 + im) * ldv_bytes + split_off(k);
             *reinterpret_cast<h8 *>(dst) = oh;
             *reinterpret_cast<h8 *>(dst + 64) = ol;
         }
@@ -537,7 +535,7 @@ __global__ void __launch_bounds__(256) lpips_tap_split_kernel(const char *__rest
 // -> the pooled activation.  The activation (1 MB per image at relu1_2) is read once instead of twice.
 template <bool H1, int C>
 __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *__restrict__ f, int64_t n, int H, int W, const float *__restrict__ coef,
-                                                                   char *__restrict__ V, int64_t ldv_bytes, int64_t off, char *__restrict__ pooled, float tap_eps)
+                                                                   char *__restrict__ V, int64_t ldv_bytes, int64_t off, char *__restrict__ pooled, float tap_eps, int64_t row0)
 {
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     constexpr int G = C / 8;            // lanes per window
@@ -576,7 +574,6 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
             ss = tap_sumsq_across<G>(ss);
             if (!live) continue;
             const float inv = __fdiv_rn(kVScale, __fadd_rn(__fsqrt_rn(ss), tap_eps));        // (A f) / (|A f| + A eps) = f / (|f| + eps)
-            char *row = V + im * ldv_bytes;
             const int64_t k = off + pin * C + cb * 8;
             h8 oh, ol;
 #pragma unroll
@@ -586,9 +583,9 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
                 ol[j] = (_Float16)__fsub_rn(t, (float)oh[j]);
             }
             if constexpr (H1) {
-                *reinterpret_cast<h8 *>(row + k * 2) = oh;
+                *reinterpret_cast<h8 *>(gl_vrow_elem(V, ldv_bytes, row0 + im, k)) = oh;
             } else {
-                char *dst = row + split_off(k);
+                char *dst = V + (row0 + im) * ldv_bytes + split_off(k);
                 *reinterpret_cast<h8 *>(dst) = oh;
                 *reinterpret_cast<h8 *>(dst + 64) = ol;
             }
@@ -606,26 +603,26 @@ __global__ void __launch_bounds__(256) lpips_tap_pool_split_kernel(const char *_
 int stream_blocks(int64_t items);
 
 template <bool H1>
-void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, const float *coef, char *V, int64_t ldv, int64_t off, float eps)
+void launch_tap_split(hipStream_t st, const char *f, int64_t n, int HW, int C, const float *coef, char *V, int64_t ldv, int64_t off, float eps, int64_t row0)
 {
     const dim3 grid((unsigned)stream_blocks(n * HW * (C / 8)));
     switch (C) {
-    case 64: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
-    case 128: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
-    case 256: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
-    default: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps); break;
+    case 64: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps, row0); break;
+    case 128: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps, row0); break;
+    case 256: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps, row0); break;
+    default: hipLaunchKernelGGL((lpips_tap_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, HW, coef, V, ldv, off, eps, row0); break;
     }
 }
 
 template <bool H1>
-void launch_tap_pool_split(hipStream_t st, const char *f, int64_t n, int H, int W, int C, const float *coef, char *V, int64_t ldv, int64_t off, char *pooled, float eps)
+void launch_tap_pool_split(hipStream_t st, const char *f, int64_t n, int H, int W, int C, const float *coef, char *V, int64_t ldv, int64_t off, char *pooled, float eps, int64_t row0)
 {
     const dim3 grid((unsigned)stream_blocks(n * (H / 2) * (W / 2) * (C / 8)));
     switch (C) {
-    case 64: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
-    case 128: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
-    case 256: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
-    default: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps); break;
+    case 64: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 64>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps, row0); break;
+    case 128: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 128>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps, row0); break;
+    case 256: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 256>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps, row0); break;
+    default: hipLaunchKernelGGL((lpips_tap_pool_split_kernel<H1, 512>), grid, dim3(256), 0, st, f, n, H, W, coef, V, ldv, off, pooled, eps, row0); break;
     }
 }
 
@@ -1009,9 +1006,10 @@ __device__ __forceinline__ void cluster_meet(unsigned *counter, unsigned target)
 __global__ void __launch_bounds__(512, 2)
 feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                     const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
-                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, int members, float inv_s2)
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, int members, float inv_s2, int blocked)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t kstep = blocked ? 32768 : 128;        // bytes between consecutive K slices of a tile's rows (K-blocked rows: gl_conv.h)
     const int cluster = blockIdx.x & (kClusters - 1), member = blockIdx.x >> 3;
     unsigned *counter = reinterpret_cast<unsigned *>(scratch) + cluster * 32;           // 128 B apart
     v4f *totals = reinterpret_cast<v4f *>(scratch + 4096 + (size_t)blockIdx.x * kTotalsPerWg);
@@ -1033,8 +1031,13 @@ feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ ban
         const int64_t n0 = (int64_t)nt * GT, q0 = (int64_t)qt * GT;
         gl_pair256::Source sa = {}, sb = {};
         if (active) {
-            sa = gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
-            sb = gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
+            if (blocked) {
+                sa = gl_pair256::make_source_blocked(bank, n0, nk, wave, lane);
+                sb = gl_pair256::make_source_blocked(query, q0, nk, wave, lane);
+            } else {
+                sa = gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
+                sb = gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
+            }
         }
         v4f acc[8][4];
 #pragma unroll
@@ -1047,7 +1050,7 @@ feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ ban
             const int64_t k0 = (int64_t)seg * kSegSlices;
             const int64_t len = nk - k0 < kSegSlices ? nk - k0 : kSegSlices;
             gl_pair256::mainloop<v8h>(sa, sb, len, smem, acc, wave, lane,
-                                      [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }, k0 * 128);
+                                      [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }, k0 * kstep, kstep);
             __syncthreads();                             // all fragment reads of the segment are done before its buffers are refilled
             if (nseg > 1) {
                 // totals (+)= accumulators; the last segment leaves the sum in the accumulators
@@ -1095,9 +1098,10 @@ feat_knn_h1c_kernel(const char *__restrict__ bank, const float *__restrict__ ban
 __global__ void __launch_bounds__(512, 2)
 feat_knn_h1s_kernel(const char *__restrict__ bank, const float *__restrict__ bank_norm, int64_t n_rows, int64_t index_base,
                     const char *__restrict__ query, const float *__restrict__ query_norm, int64_t nq, int64_t K1,
-                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, float inv_s2)
+                    unsigned long long *__restrict__ keys, int q_tiles, int n_tiles, char *__restrict__ scratch, float inv_s2, int blocked)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int64_t kstep = blocked ? 32768 : 128;
     v4f *totals = reinterpret_cast<v4f *>(scratch + 4096 + (size_t)blockIdx.x * kTotalsPerWg);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1119,8 +1123,8 @@ feat_knn_h1s_kernel(const char *__restrict__ bank, const float *__restrict__ ban
             qt = (int)(r / (unsigned)width);
         }
         const int64_t n0 = (int64_t)nt * GT, q0 = (int64_t)qt * GT;
-        const gl_pair256::Source sa = gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
-        const gl_pair256::Source sb = gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
+        const gl_pair256::Source sa = blocked ? gl_pair256::make_source_blocked(bank, n0, nk, wave, lane) : gl_pair256::make_source(bank, n0, n_rows, K1 * 2, wave, lane);
+        const gl_pair256::Source sb = blocked ? gl_pair256::make_source_blocked(query, q0, nk, wave, lane) : gl_pair256::make_source(query, q0, nq, K1 * 2, wave, lane);
         v4f acc[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1130,7 +1134,7 @@ feat_knn_h1s_kernel(const char *__restrict__ bank, const float *__restrict__ ban
             const int64_t k0 = (int64_t)seg * kSegSlices;
             const int64_t len = nk - k0 < kSegSlices ? nk - k0 : kSegSlices;
             gl_pair256::mainloop<v8h>(sa, sb, len, smem, acc, wave, lane,
-                                      [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }, k0 * 128);
+                                      [](const v8h &a, const v8h &b, const v4f &c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }, k0 * kstep, kstep);
             __syncthreads();
             if (nseg > 1) {
 #pragma unroll
@@ -1407,7 +1411,11 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
 
     for (int64_t i0 = 0; i0 < n; i0 += l->ws_imgs) {
         const int64_t m = (n - i0 < l->ws_imgs) ? n - i0 : l->ws_imgs;
-        char *Vc = reinterpret_cast<char *>(V_dev) + i0 * ldv;
+        char *Vc = reinterpret_cast<char *>(V_dev) + i0 * ldv;       // split rows (fmt 0): this pass's first row
+        // fp16 search rows: the writers address the whole buffer by (row, k) -- row-major, or K-blocked for long rows (gl_conv.h gl_vrow_elem)
+        char *Vw = fmt ? reinterpret_cast<char *>(V_dev) : Vc;
+        const int64_t rw = fmt ? i0 : 0;
+        const int64_t ldw = (fmt && gl_vrow_blocked(ldv / 2)) ? -(ldv / 128) : ldv;
         const bool h3 = l->precision == 1;
         const float *cur = nullptr;
         float *bufs[2] = {l->ws_a, l->ws_b};
@@ -1450,7 +1458,7 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 if (kAfter[ci] == 2 && gl_conv_h3_tap_fusable(p, 1)) {
                     // tap + 2x2 max-pool in the convolution's epilogue: the full-resolution activation is never stored
                     const int C = kCout[ci];
-                    p.tap_V = Vc; p.tap_coef = l->ws_coef + coef_off; p.tap_ldv = ldv; p.tap_off = off; p.tap_fmt = fmt ? 1 : 0;
+                    p.tap_V = Vw; p.tap_coef = l->ws_coef + coef_off; p.tap_ldv = ldw; p.tap_row0 = rw; p.tap_off = off; p.tap_fmt = fmt ? 1 : 0;
                     p.tap_pool = reinterpret_cast<char *>(bufs[which]); p.tap_scale = kVScale; p.tap_eps = kTapEps1 * l->act[ci];
                     rc = gl_launch_gather_conv_h3(ctx, p, 1);
                     if (rc != GL_OK) return rc;
@@ -1477,11 +1485,11 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 // tap + 2x2 max-pool in one pass over the activation
                 const int C = kCout[ci];
                 if (fmt)
-                    launch_tap_pool_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vc, ldv, off,
-                                                reinterpret_cast<char *>(bufs[which]), kTapEps1 * l->act[ci]);
+                    launch_tap_pool_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vw, ldw, off,
+                                                reinterpret_cast<char *>(bufs[which]), kTapEps1 * l->act[ci], rw);
                 else
-                    launch_tap_pool_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vc, ldv, off,
-                                                 reinterpret_cast<char *>(bufs[which]), kTapEps1 * l->act[ci]);
+                    launch_tap_pool_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h, w, C, l->ws_coef + coef_off, Vw, ldw, off,
+                                                 reinterpret_cast<char *>(bufs[which]), kTapEps1 * l->act[ci], rw);
                 GL_LAUNCH_CHECK();
                 off += (int64_t)C * h * w;
                 coef_off += C;
@@ -1494,13 +1502,13 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
                 const int C = kCout[ci];
                 const dim3 tg((unsigned)stream_blocks(m * h * w * 64));
                 if (h3 && fmt)
-                    launch_tap_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off, kTapEps1 * l->act[ci]);
+                    launch_tap_split<true>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vw, ldw, off, kTapEps1 * l->act[ci], rw);
                 else if (h3)
-                    launch_tap_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off, kTapEps1 * l->act[ci]);
+                    launch_tap_split<false>(ctx->stream, reinterpret_cast<const char *>(cur), m, h * w, C, l->ws_coef + coef_off, Vw, ldw, off, kTapEps1 * l->act[ci], rw);
                 else if (fmt)
-                    hipLaunchKernelGGL(lpips_tap_kernel<true>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
+                    hipLaunchKernelGGL(lpips_tap_kernel<true>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vw, ldw, off, rw);
                 else
-                    hipLaunchKernelGGL(lpips_tap_kernel<false>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vc, ldv, off);
+                    hipLaunchKernelGGL(lpips_tap_kernel<false>, tg, dim3(256), 0, ctx->stream, cur, m, h * w, C, l->ws_coef + coef_off, Vw, ldw, off, rw);
                 GL_LAUNCH_CHECK();
                 off += (int64_t)C * h * w;
                 coef_off += C;
@@ -1523,17 +1531,17 @@ int lpips_features_impl(gl_lpips *l, const T *img_dev, int64_t n, int H, int W, 
             if (lattice) {
                 if constexpr (sizeof(T) == 1)
                     hipLaunchKernelGGL(image_part_lattice_kernel, dim3((unsigned)stream_blocks(m * (Dp + pad))), dim3(256), 0, ctx->stream,
-                                       reinterpret_cast<const uint8_t *>(img_dev) + i0 * D, m, D, Dp + pad, (float)std::ldexp(1.0, lp_lattice_exp(D)), Vc, ldv, K_lp);
+                                       reinterpret_cast<const uint8_t *>(img_dev) + i0 * D, m, D, Dp + pad, (float)std::ldexp(1.0, lp_lattice_exp(D)), Vw, ldw, K_lp, rw);
             } else {
                 hipLaunchKernelGGL(image_part_h1_kernel<T>, dim3((unsigned)stream_blocks(m * Dp)), dim3(256), 0, ctx->stream, img_dev + i0 * D, m, D, Dp,
-                                   (float)(1.0 / std::sqrt((double)D)), Vc, ldv, K_lp, lo_seg, (int)pad);
+                                   (float)(1.0 / std::sqrt((double)D)), Vw, ldw, K_lp, lo_seg, (int)pad, rw);
             }
             GL_LAUNCH_CHECK();
             {
                 // partial sums go to the first activation buffer, which is free by now (m * nseg doubles)
                 const int nseg = (int)gl_ceil_div(K_lp + Dp, kNormSeg);
                 double *part = reinterpret_cast<double *>(l->ws_a);
-                hipLaunchKernelGGL(row_sqnorm_h1_part_kernel, dim3((unsigned)nseg, (unsigned)m), dim3(256), 0, ctx->stream, Vc, ldv, K_lp, Dp, lo_seg, nseg, part);
+                hipLaunchKernelGGL(row_sqnorm_h1_part_kernel, dim3((unsigned)nseg, (unsigned)m), dim3(256), 0, ctx->stream, Vw, ldw, K_lp, Dp, lo_seg, nseg, part, rw);
                 GL_LAUNCH_CHECK();
                 hipLaunchKernelGGL(row_sqnorm_h1_final_kernel, dim3((unsigned)gl_ceil_div(m, 256)), dim3(256), 0, ctx->stream, part, m, nseg,
                                    1.0 / (row_scale * row_scale), norms_dev + i0);
@@ -1708,6 +1716,8 @@ int64_t gl_lpips_lattice_dim(int H, int W)
     return k - D + Dp + lp_search_pad(k - D, Dp, 1);
 }
 
+int64_t gl_lpips_search_rows_capacity(int64_t n, int64_t K1) { return n < 0 || K1 <= 0 ? -1 : gl_vrow_capacity(n, K1); }
+
 float gl_lpips_lattice_scale(int H, int W) { return H > 0 && W > 0 ? (float)lp_lattice_scale(3ll * H * W) : 0.0f; }
 
 int gl_lpips_lattice_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, void *V16_dev, float *norms_dev)
@@ -1747,7 +1757,10 @@ int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *ba
     gl_prof_scope prof_(ctx, GL_PROF_FEAT_KNN);
     // variant 3: the persistent cluster form (needs 32 workgroup slots per cluster, i.e. a whole MI355X); 5: the persistent form without clusters
     // (what a device with fewer compute units gets -- the same bits).  Tuning builds add 0 / 1 / 2 / 4: the one-workgroup-per-tile kernels.
-    const int variant = gl_tuning_int("GL_PAIR_VARIANT", 3);
+    // long rows are K-blocked (gl_conv.h gl_vrow_blocked: decided by the row length alone, the same rule the feature writers use); the buffers
+    // then hold whole blocks of 256 rows
+    const int blocked = gl_vrow_blocked(K1) ? 1 : 0;
+    const int variant = blocked ? 3 : gl_tuning_int("GL_PAIR_VARIANT", 3);
     const int members = ctx->num_cu / kClusters;
     const bool clustered = variant == 3 && members >= kSuperN * kSuperQ;
     if (clustered || variant == 3 || variant == 5) {
@@ -1767,11 +1780,11 @@ int gl_feat_knn_h1_scaled(gl_ctx *ctx, const void *bank_V16_dev, const float *ba
             GL_HIP(hipMemsetAsync(ctx->pair_scratch, 0, 4096, ctx->stream));         // the cluster counters
             hipLaunchKernelGGL(feat_knn_h1c_kernel, dim3((unsigned)grid), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
                                bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
-                               reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members, inv_s2);
+                               reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, members, inv_s2, blocked);
         } else {
             hipLaunchKernelGGL(feat_knn_h1s_kernel, dim3((unsigned)grid), dim3(512), lds, ctx->stream, reinterpret_cast<const char *>(bank_V16_dev),
                                bank_norm_dev, n_rows, index_base, reinterpret_cast<const char *>(query_V16_dev), query_norm_dev, nq, K1,
-                               reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, inv_s2);
+                               reinterpret_cast<unsigned long long *>(keys_dev), (int)q_tiles, (int)n_tiles, ctx->pair_scratch, inv_s2, blocked);
         }
         GL_LAUNCH_CHECK();
         return GL_OK;
@@ -1918,8 +1931,8 @@ int gl_fbb_knn_lpips_host(gl_ctx *ctx, gl_lpips *l, const uint8_t *bank_u8_host,
     };
 #define GL_TRY(e) do { rc = (e); if (rc != GL_OK) goto done; } while (0)
     GL_TRY(gl_malloc(ctx, (size_t)((chunk > nq ? chunk : nq) * D), (void **)&raw));
-    GL_TRY(gl_malloc(ctx, (size_t)(nq * row), &qV));
-    GL_TRY(gl_malloc(ctx, (size_t)(chunk * row), &bV));
+    GL_TRY(gl_malloc(ctx, (size_t)(gl_vrow_capacity(nq, K1) * row), &qV));          // long rows are K-blocked: whole blocks of 256 rows
+    GL_TRY(gl_malloc(ctx, (size_t)(gl_vrow_capacity(chunk, K1) * row), &bV));
     GL_TRY(gl_malloc(ctx, (size_t)nq * 4, (void **)&qn));
     GL_TRY(gl_malloc(ctx, (size_t)chunk * 4, (void **)&bn));
     GL_TRY(gl_malloc(ctx, (size_t)nq * 8, (void **)&keys));

@@ -54,6 +54,23 @@ __device__ __forceinline__ Source make_source(const char *rows, int64_t row0, in
     return s;
 }
 
+// The same for rows in the K-blocked layout (gl_conv.h gl_vrow_elem: [row / 256][K / 64][row % 256][128 B]; row0 is a multiple of 256): the
+// K slice of a tile is one contiguous 32 KiB piece, a wave's piece i its rows (4w+i)*8 .. +7, i.e. 1 KiB of it.  Consecutive slices of a tile lie
+// 32 KiB apart (the caller passes kstep = 32768 to mainloop instead of ROW); a block of 256 rows is `cells` * 32 KiB long.  The buffer holds whole blocks, so no row is clamped; rows
+// beyond `valid` are whatever the buffer holds and the epilogue masks them.
+__device__ __forceinline__ Source make_source_blocked(const char *rows, int64_t row0, int64_t cells, int wave, int lane)
+{
+    Source s;
+    const int rsub = lane >> 3, slot = lane & 7;
+    const char *tile = rows + (row0 >> 8) * cells * 32768;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s.base[i] = tile + (wave * 4 + i) * 1024;
+        s.off[i] = (uint32_t)(rsub * 128 + ((slot ^ rsub) << 4));
+    }
+    return s;
+}
+
 __device__ __forceinline__ void stage(const Source &a, const Source &b, int64_t kbyte, char *buf, int wave)
 {
 #pragma unroll
@@ -76,7 +93,7 @@ __device__ __forceinline__ void stage_piece(const Source &a, const Source &b, in
 // SPREAD: the 8 DMA pieces of a slice are issued one (8) or two (4) per group of 4 MFMAs after the barrier, or all at once (1)
 template <typename Frag, int DIAG = 0, int SPREAD = 8, typename Acc, typename Mfma>
 __device__ __forceinline__ void mainloop(const Source &sa, const Source &sb, int64_t nk, char *smem, Acc (&acc)[8][4], int wave, int lane, Mfma mfma,
-                                         int64_t kbyte0 = 0)
+                                         int64_t kbyte0 = 0, int64_t kstep = ROW)
 {
     const int wn = wave >> 2, wq = wave & 3;
     const int frow = lane & 15, fk = lane >> 4;
@@ -124,7 +141,7 @@ __device__ __forceinline__ void mainloop(const Source &sa, const Source &sb, int
     if (nk <= 0) return;
     stage(sa, sb, kbyte0, smem, wave);
     if (nk > 1) {
-        stage(sa, sb, kbyte0 + ROW, smem + SLICE, wave);
+        stage(sa, sb, kbyte0 + kstep, smem + SLICE, wave);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // slice 0 landed, the 8 DMAs of slice 1 stay in flight
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -135,7 +152,7 @@ __device__ __forceinline__ void mainloop(const Source &sa, const Source &sb, int
     for (int64_t kt = 0; kt < nk; ++kt) {
         const uint32_t cur = (uint32_t)(kt & 1) * SLICE, nxt = SLICE - cur;
         const bool more = kt + 2 < nk;
-        const int64_t kb = kbyte0 + (DIAG == 4 ? (kt & 1) * ROW : (kt + 2) * ROW);
+        const int64_t kb = kbyte0 + (DIAG == 4 ? (kt & 1) * kstep : (kt + 2) * kstep);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // set0 (read during the previous half slice) is in
         __builtin_amdgcn_sched_barrier(0);
         // ---- first half: 32 MFMAs on set0 (k-step 0 of slice kt); k-step 1 is read into set1 two fragments per group

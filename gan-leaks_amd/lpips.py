@@ -49,6 +49,20 @@ class FeatureBank:
         self.fmt = fmt if role is not None else None
         self.scale = float(scale)
 
+    @property
+    def blocked(self):
+        """fp16 search rows of 2 MiB or more (images from 96 x 96) are stored K-blocked -- [row / 256][K / 64][row % 256][64 halves], see
+        include/ganleaks.h gl_lpips_search_rows_capacity -- and their buffer holds whole blocks of 256 rows"""
+        return self.role is not None and self.K * 2 >= (2 << 20)
+
+    def rows_numpy(self):
+        """the n rows as a host array [n, K] whatever the device layout (tests / tools)"""
+        raw = self.V.numpy()
+        if not self.blocked:
+            return raw.reshape(-1, self.K)[:self.n]
+        nb = raw.size // (256 * self.K)
+        return raw.reshape(nb, self.K // 64, 256, 64).transpose(0, 2, 1, 3).reshape(nb * 256, self.K)[:self.n]
+
     def __len__(self):
         return self.n
 
@@ -161,16 +175,17 @@ class LpipsModel:
         lattice = fmt == "lattice"
         K1 = K if role is None else int(ctx.lib.gl_lpips_lattice_dim(H, W) if lattice else ctx.lib.gl_lpips_search_dim(H, W))
         scale = float(ctx.lib.gl_lpips_lattice_scale(H, W)) if lattice else 16384.0
+        cap = n if role is None else int(ctx.lib.gl_lpips_search_rows_capacity(max(n, 1), K1))      # long search rows: whole blocks of 256
         if out is not None:
-            if getattr(out, "role", None) != role or getattr(out, "fmt", None) != fmt or out.K != K1 or out.V.shape[0] < n:
+            if getattr(out, "role", None) != role or getattr(out, "fmt", None) != fmt or out.K != K1 or out.V.shape[0] < cap:
                 raise ValueError("features(out=...): buffer of another role / layout / image size, or too small")
             V, norms = out.V, out.norms
         elif role is None:
             V = ctx.empty((max(n, 1), K), np.float32)
             norms = ctx.empty((max(n, 1),), np.float32)
         else:
-            V = ctx.empty((max(n, 1), K1), np.float16)
-            norms = ctx.empty((max(n, 1),), np.float32)
+            V = ctx.empty((max(cap, 1), K1), np.float16)
+            norms = ctx.empty((max(cap, 1),), np.float32)
         r = 0 if role == "query" else 1
 
         def run():
@@ -212,11 +227,13 @@ def features_sharded(model, images_u8, comm):
     scale = float(ctx.lib.gl_lpips_lattice_scale(H, W))
     world, rank = int(comm.nranks), int(comm.rank)
     per = -(-Q // world)
+    if K1 * 2 >= (2 << 20):
+        per = -(-per // 256) * 256                    # K-blocked rows: a rank's block is whole blocks of 256 rows (contiguous bytes)
     V = ctx.empty((world * per, K1), np.float16)
     norms = ctx.empty((world * per,), np.float32)
     lo, hi = min(rank * per, Q), min((rank + 1) * per, Q)
     if hi > lo:
-        mine = FeatureBank(ctx, V.view((hi - lo, K1), offset_bytes=lo * K1 * 2), norms.view((hi - lo,), offset_bytes=lo * 4), hi - lo, K1,
+        mine = FeatureBank(ctx, V.view((per, K1), offset_bytes=lo * K1 * 2), norms.view((per,), offset_bytes=lo * 4), hi - lo, K1,
                            K - 3 * H * W, 0, "query", "lattice", scale)
         model.features(images_u8[lo:hi], role="query", fmt="lattice", out=mine)
     comm.allgather_rows(V, per * K1 * 2)

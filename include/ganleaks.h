@@ -307,6 +307,15 @@ int gl_lpips_search_features_f32(gl_lpips *l, const float *img_f32_dev, int64_t 
  * layout.  Search with gl_feat_knn_h1_scaled(..., K1 = gl_lpips_lattice_dim, row_scale = gl_lpips_lattice_scale). */
 int64_t gl_lpips_lattice_dim(int H, int W);
 float gl_lpips_lattice_scale(int H, int W);
+/* MEMORY LAYOUT of fp16 search rows (both forms: gl_lpips_search_dim / gl_lpips_lattice_dim halves per row = K1), decided by K1 alone so that the
+ * writers (gl_lpips_*_features_*) and the search (gl_feat_knn_h1*) agree without a flag:
+ *   K1 * 2 <  2 MiB (images up to ~80 x 80) : row-major, V16_dev[row * K1 + k]
+ *   K1 * 2 >= 2 MiB (96 x 96 and larger)   : K-blocked, half k of row r at byte ((r / 256) * (K1 / 64) + k / 64) * 32768 + (r % 256) * 128 + (k % 64) * 2
+ *     -- the search reads the same 128-byte K slice of a tile's 256 + 256 rows together; with 16 MiB rows that is 512 different 2 MiB pages per slice
+ *     (measured: 44 % of the TLB lookups missed, the kernel ran 17 % below its 64 x 64 rate); blocked, it is two contiguous 32 KiB pieces.
+ * A buffer for n rows must hold gl_lpips_search_rows_capacity(n, K1) rows (n, or n rounded up to a multiple of 256), and V16_dev must point at a
+ * multiple of 256 rows of its buffer when blocked.  Rows are opaque to callers either way (only |row|^2 and the keys come back). */
+int64_t gl_lpips_search_rows_capacity(int64_t n, int64_t K1);
 int gl_lpips_lattice_features_u8(gl_lpips *l, const uint8_t *img_u8_dev, int64_t n, int H, int W, void *V16_dev, float *norms_dev);
 
 /* gl_feat_knn on search rows: same keys, one fp16 MFMA per product, 256 x 256 tiles.  K1 = gl_lpips_search_dim.

@@ -343,7 +343,7 @@ def test_feature_rows_do_not_depend_on_the_pass_size(role, res, n, passes, gl, s
         m = LpipsModel().load_state_dicts(synth.vgg16_state_dict(7), lin)
         m.set_chunk(per_pass)
         fb = m.features(imgs, role=role)
-        rows[per_pass] = (fb.V.numpy().copy(), fb.norms.numpy().copy())
+        rows[per_pass] = ((fb.rows_numpy() if role else fb.V.numpy()).copy(), fb.norms.numpy()[:n].copy())
     for per_pass in passes[1:]:
         assert np.array_equal(rows[passes[0]][0].view(np.uint8), rows[per_pass][0].view(np.uint8)), \
             "V differs between passes of %d and %d images" % (passes[0], per_pass)
@@ -418,7 +418,7 @@ def test_split_path_on_weights_with_imagenet_like_dynamic_range(gl, synth, lin, 
     b = LpipsModel().load_state_dicts(sd, lin)
     b.features(rng.integers(0, 256, size=(3, 3, 64, 64), dtype=np.uint8), role="bank")
     va, vb = a.features(bank, role="bank"), b.features(bank, role="bank")
-    assert np.array_equal(va.V.numpy(), vb.V.numpy()) and np.array_equal(va.norms.numpy(), vb.norms.numpy())
+    assert np.array_equal(va.rows_numpy(), vb.rows_numpy()) and np.array_equal(va.norms.numpy(), vb.norms.numpy())
     # and the search on these weights agrees with the oracle's nearest neighbours
     od, oi, _ = lpips_oracle.knn_l2_lpips(sd, lins, f(bank), f(q), 16)
     d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=a)

@@ -181,12 +181,12 @@ def test_sharded_query_features_equal_replicated_ones(synth, golden_dir):
         for rank in (0, world - 1):
             fb = lp.features_sharded(model, q, Stand_in(rank, world))
             assert fb.n == len(q) and fb.K == K1 and fb.fmt == "lattice" and fb.role == "query"
-            assert np.array_equal(fb.V.numpy()[:len(q)], full.V.numpy()) and np.array_equal(fb.norms.numpy()[:len(q)], full.norms.numpy()), (world, rank)
+            assert np.array_equal(fb.rows_numpy(), full.rows_numpy()) and np.array_equal(fb.norms.numpy()[:len(q)], full.norms.numpy()), (world, rank)
     # more ranks than queries would leave ranks empty: prepare_queries keeps such small sets replicated
     one = Comm(ctx, Comm.unique_id(), 0, 1)
     fb1 = lp.features_sharded(model, q, one)                       # the real ncclAllGather, one rank: in-place
     ctx.sync()
-    assert np.array_equal(fb1.V.numpy(), full.V.numpy()) and np.array_equal(fb1.norms.numpy(), full.norms.numpy())
+    assert np.array_equal(fb1.rows_numpy(), full.rows_numpy()) and np.array_equal(fb1.norms.numpy()[:len(q)], full.norms.numpy())
     assert prepare_queries(q, "l2-lpips", ctx, model, comm=one).V.shape[0] == len(q)     # one rank: the replicated form
     one.destroy()
     with pytest.raises(ValueError):

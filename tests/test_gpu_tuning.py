@@ -74,7 +74,7 @@ for v in (1, 0):
     os.environ["GL_H3_T4"] = str(v)
     f32, u8 = g.forward_device(z, True, True)
     fb = m.features(imgs, role="bank")
-    res[v] = (f32.numpy().copy(), u8.numpy().copy(), fb.V.numpy().copy(), fb.norms.numpy().copy())
+    res[v] = (f32.numpy().copy(), u8.numpy().copy(), fb.rows_numpy().copy(), fb.norms.numpy().copy())
 out["t4_equals_raster"] = [bool(np.array_equal(a, b)) for a, b in zip(res[1], res[0])]
 print("RESULT " + json.dumps(out))
 '''
