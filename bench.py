@@ -531,6 +531,61 @@ def measure(job, args, distance, gen_precision, steps, warmup, cpu_leg, headline
     return line
 
 
+def live_traffic(args, distance, gen_precision):
+    """HBM-side bytes per launch of every kernel family of ONE step of this workload, measured now: two child runs of this file under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes, never together with a trace, as MI355X_MICROARCH.md prescribes), summed per
+    family by tools/pmc_summary.py: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both counters are in KiB; on gfx950 FETCH_SIZE reports half of a wide
+    coalesced read stream).  Returns {family: bytes per launch} or None when the profiler is not available / fails (the caller then falls back to
+    the committed passes)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    tmp = tempfile.mkdtemp(prefix="gl_traffic_", dir="/tmp")
+    try:
+        cmd = ["python3", os.path.join(ROOT, "bench.py"), "--secondary", "off", "--steps", "1", "--warmup", "0", "--cpu-queries", "0", "--check-queries", "0",
+               "--live-traffic", "off", "--distance", distance, "--gen-precision", str(gen_precision), "--queries", str(args.queries), "--bank", str(args.bank)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        dirs = []
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter.lower())
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=600)
+            if r.returncode != 0:
+                return None
+            dirs.append(d)
+        out = os.path.join(tmp, "summary.json")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), out] + dirs, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        if r.returncode != 0:
+            return None
+        with open(out) as f:
+            tr = json.load(f)
+        return {k: v["hbm_bytes_per_launch"] for k, v in tr.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
+    except Exception as e:  # noqa: BLE001  (a measurement aid: never fails the bench)
+        log("[traffic] live PMC passes failed: %s" % (e,))
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def apply_live_traffic(line, tr):
+    """put the measured bytes per launch into a bench line's kernel entries and its roofline block"""
+    if not tr:
+        return False
+    hit = False
+    for k in line.get("kernels", []):
+        fam = k["kernel"] if k["kernel"] in tr else k["kernel"] + "_f32"       # the fp32-MFMA convolution kernel is its own family in the summary
+        if fam in tr:
+            k["traffic"] = round(tr[fam])
+            k["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (tools/pmc_summary.py)"
+            if k["kernel"] == line["roofline"].get("kernel"):
+                line["roofline"]["traffic"] = k["traffic"]
+                line["roofline"]["traffic_source"] = k["traffic_source"]
+                hit = True
+    return hit
+
+
 def measure_config0(job, args):
     """BASELINE configs[0]: DCGAN-64, 256 queries x 1 000 samples, L2 -- the reference's own CPU-runnable case (plumbing).  CPU: the full run of
     the torch restatement of fbb.custom_knn, wall clock, median of 3.  GPU: the same problem through attack() (bank
@@ -604,6 +659,9 @@ def main():
                     help="the two further measurements (configs[2] under 0.2*LPIPS+L2, and the fp32-MFMA generator): auto = with the default one-GPU "
                          "headline workload only")
     ap.add_argument("--secondary-steps", type=int, default=2)
+    ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic from rocprofv3 --pmc passes of child runs of this workload made now (auto: in the default one-GPU run only); "
+                         "otherwise, and when the profiler is unavailable, from the newest committed passes under profiles/")
     args = ap.parse_args()
     if args.backend == "nccl":
         args.collective = "torch"
@@ -624,6 +682,17 @@ def main():
                 "parity", "auroc", "speedup_vs_cpu_baseline")
         line["secondary"] = {k: sec[k] for k in keep + ("cpu_baseline_features_once", "speedup_vs_cpu_features_once", "algorithmic_speedup_on_cpu") if k in sec}
         line["config0"] = measure_config0(job, args)
+    live = job.world == 1 and (args.live_traffic == "on" or (args.live_traffic == "auto" and default_run))
+    if live:
+        import gc
+        gc.collect()
+        job.ctx.trim()                                           # the children need the memory this process has released
+        t0 = time.time()
+        ok = apply_live_traffic(line, live_traffic(args, args.distance, args.gen_precision))
+        if default_run:
+            ok = apply_live_traffic(line["secondary"], live_traffic(args, "l2-lpips", 1)) and ok
+            apply_live_traffic(line["secondary_fp32"], live_traffic(args, "l2", 0))
+        log("[traffic] live PMC passes %s in %.0fs" % ("ok" if ok else "unavailable: committed passes kept", time.time() - t0))
         line["secondary_fp32"] = {k: f32[k] for k in keep if k != "cpu_baseline" and k != "speedup_vs_cpu_baseline"}
     if job.rank == 0:
         print(json.dumps(line), flush=True)

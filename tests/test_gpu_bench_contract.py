@@ -57,6 +57,9 @@ def test_bench_line_with_secondary_measurements():
     c0 = d["config0"]                            # BASELINE configs[0]: 256 x 1k, L2, CPU full run (median of 3) beside the device
     assert "configs[0]" in c0["workload"] and c0["parity"]["idx_equal"] is True and c0["parity"]["max_abs_dist_err"] < 1e-6
     assert c0["cpu_baseline"]["cores"] >= 1 and c0["cpu_baseline"]["value"] > 0 and "median of 3" in c0["cpu_baseline"]["sample"]
+    # roofline.traffic of the default run is measured now (child runs under rocprofv3 --pmc), not copied from a committed file
+    for blk in (d, s):
+        assert isinstance(blk["roofline"]["traffic"], int) and blk["roofline"]["traffic"] > 0 and blk["roofline"]["traffic_source"].startswith("live"), blk["roofline"]
     f = d["secondary_fp32"]
     assert f["dtype"].startswith("f32") and f["roofline"]["peak"] == 157.3 and f["parity"]["idx_equal"] is True
     assert f["ms_per_step"] > 0 and "cpu_baseline" not in f
