@@ -681,6 +681,7 @@ def main():
         keep = ("value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "cpu_baseline", "kernels", "phases_ms_per_step_rank0",
                 "parity", "auroc", "speedup_vs_cpu_baseline")
         line["secondary"] = {k: sec[k] for k in keep + ("cpu_baseline_features_once", "speedup_vs_cpu_features_once", "algorithmic_speedup_on_cpu") if k in sec}
+        line["secondary_fp32"] = {k: f32[k] for k in keep if k != "cpu_baseline" and k != "speedup_vs_cpu_baseline"}
         line["config0"] = measure_config0(job, args)
     live = job.world == 1 and (args.live_traffic == "on" or (args.live_traffic == "auto" and default_run))
     if live:
@@ -693,7 +694,6 @@ def main():
             ok = apply_live_traffic(line["secondary"], live_traffic(args, "l2-lpips", 1)) and ok
             apply_live_traffic(line["secondary_fp32"], live_traffic(args, "l2", 0))
         log("[traffic] live PMC passes %s in %.0fs" % ("ok" if ok else "unavailable: committed passes kept", time.time() - t0))
-        line["secondary_fp32"] = {k: f32[k] for k in keep if k != "cpu_baseline" and k != "speedup_vs_cpu_baseline"}
     if job.rank == 0:
         print(json.dumps(line), flush=True)
     if job.world > 1:
