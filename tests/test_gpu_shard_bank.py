@@ -191,3 +191,30 @@ def test_sharded_query_features_equal_replicated_ones(synth, golden_dir):
     one.destroy()
     with pytest.raises(ValueError):
         lp.features_sharded(model, q.astype(np.float32), Stand_in(0, 2))
+
+
+def test_fbb_sweep_on_a_device_group(tmp_path, monkeypatch, synth):
+    """fbb.py --hyperparameter_search --devices ...: one DeviceGroup serves every bank of the sweep (attack_models/fbb.py:114-123 walks the
+    sub-folders), the results equal the single-device sweep's file for file"""
+    import PIL.Image
+    from ganleaks_amd.attack_models import fbb
+    banks = {"lr_0.1": synth.lowpass_u8_images(41, 130, 16), "lr_0.2": synth.lowpass_u8_images(42, 70, 16)}
+    pos = synth.perturb_u8(43, banks["lr_0.1"][[0, 64, 127]], 2.0)
+    neg = synth.lowpass_u8_images(44, 4, 16)
+    sweep = tmp_path / "png_images" / "lr"
+    for name, imgs in list(banks.items()) + [("pos", pos), ("neg", neg)]:
+        d = (sweep / name) if name in banks else (tmp_path / name)
+        os.makedirs(d)
+        for k, im in enumerate(imgs):
+            PIL.Image.fromarray(im.transpose(1, 2, 0)).save(d / ("image_%d.png" % k))
+    monkeypatch.chdir(tmp_path)
+    base = ["--syn_data_path", str(sweep), "--pos_data_dir", str(tmp_path / "pos"), "--neg_data_dir", str(tmp_path / "neg"), "--resolution", "16",
+            "--BATCH_SIZE", "64", "--distance", "l2", "--hyperparameter_search", "1"]
+    one = fbb.main(fbb.parse_arguments(base + ["--exp_name", "single"]))
+    two = fbb.main(fbb.parse_arguments(base + ["--exp_name", "sharded", "--devices", "0,0"]))
+    assert len(one) == len(two) == 2
+    for (d1, p1, n1, pi1, ni1), (d2, p2, n2, pi2, ni2) in zip(sorted(one), sorted(two)):
+        assert os.path.basename(d1) == os.path.basename(d2)
+        assert np.array_equal(p1, p2) and np.array_equal(n1, n2) and np.array_equal(pi1, pi2) and np.array_equal(ni1, ni2)
+    lr1 = [r for r in two if r[0].endswith("lr_0.1")][0]
+    assert list(lr1[3][:, 0]) == [0, 64, 127]
