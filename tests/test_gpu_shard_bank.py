@@ -218,7 +218,7 @@ def test_fbb_sweep_on_a_device_group(tmp_path, monkeypatch, synth):
         assert np.array_equal(p1, p2) and np.array_equal(n1, n2) and np.array_equal(pi1, pi2) and np.array_equal(ni1, ni2)
     lr1 = [r for r in two if r[0].endswith("lr_0.1")][0]
     # indices refer to the sorted() path order of the bank files (image_10 < image_2), as in the reference (utils.py:57)
-    order = sorted(range(128), key=lambda k: str(sweep / "lr_0.1" / ("image_%d.png" % k)))
+    order = sorted(range(130), key=lambda k: str(sweep / "lr_0.1" / ("image_%d.png" % k)))[:128]
     porder = sorted(range(3), key=lambda k: str(tmp_path / "pos" / ("image_%d.png" % k)))
     want = [order.index([0, 64, 127][k]) for k in porder]
     assert [int(v) for v in lr1[3][:, 0]] == want
