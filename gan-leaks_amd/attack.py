@@ -341,7 +341,7 @@ def prepare_queries(queries, distance, ctx=None, lpips=None, comm=None):
         model = lpips or _lp.default_model()
         if len(queries) * _feature_row_bytes(model.ctx, model, queries) > _budget_bytes():
             return queries
-        if (comm is not None and comm.nranks > 1 and model.search_rows == "fp16" and getattr(queries, "dtype", None) == np.uint8
+        if (comm is not None and comm.nranks > 1 and model.search_rows == "fp16" and isinstance(queries, np.ndarray) and queries.dtype == np.uint8
                 and len(queries) >= 8 * comm.nranks):
             return _lp.features_sharded(model, queries, comm)
         return model.features(queries, role=model.search_role("query"))
