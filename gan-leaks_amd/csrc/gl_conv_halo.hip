@@ -35,11 +35,17 @@ constexpr int HALO = BLK + 2;                 // 18
 constexpr int HPIX = HALO * HALO;             // 324 pixel slots
 constexpr int HPIECES = (HPIX + 7) / 8;       // 41 LDS-DMA pieces of 8 pixels (1 KiB)
 constexpr int HBYTES = HPIECES * 1024;        // 41 KiB per halo buffer
+// RING form (round 3): every wave issues the same number of halo pieces (the waits below are counted), so the buffer is padded to a whole
+// number of pieces per wave: 44 KiB for 4 waves, 48 KiB for 8; the surplus pieces are out-of-range loads (zero fill) into the padding
+constexpr int halo_bytes(int nw, bool ring) { return ring ? ((HPIECES + nw - 1) / nw) * nw * 1024 : HBYTES; }
 
 // WC waves along the channels (TC = 4 tiles of 16 each: 64 channels per wave), 4 waves along the block rows (4 rows each)
 //   <1>: 64 channels, 4 waves, one halo buffer (57 KiB of LDS, two workgroups per CU overlap each other's staging)
 //   <2>: 128 channels, 8 waves, two halo buffers (the next chunk is staged during the current one; 114 KiB, one workgroup per CU)
-template <int WC>
+// RING: the weight slices go through a ring of THREE buffers with counted waits (s_waitcnt vmcnt(N) + a raw s_barrier) instead of two buffers
+// behind __syncthreads(): the slice of tap t + 2 is requested while tap t is computed, so a tap's 48 MFMAs per wave (768 cycles at the full rate,
+// about one L2 round trip) no longer have to cover the whole latency of the next slice.  Same K order, same MFMA order: same bits.
+template <int WC, bool RING = false>
 __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGatherConv p, int blocks_x, int blocks_per_img, unsigned total_blocks)
 {
 #if __HIP_DEVICE_COMPILE__
@@ -49,8 +55,9 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
     constexpr int NHBUF = WC;                                // halo buffers
     constexpr int PH = (HPIECES + NW - 1) / NW;              // halo pieces per wave
     constexpr int PW = (HTC / 8) / NW;                       // weight pieces per wave and slice (2)
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo x NHBUF][W x 2]
-    char *const wbuf = smem + NHBUF * HBYTES;
+    constexpr int HB = halo_bytes(NW, RING);
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo x NHBUF][W x 2 (RING: x 3)]
+    char *const wbuf = smem + NHBUF * HB;
 
     const unsigned id = gl_xcd_remap(blockIdx.x, total_blocks);
     const int img = (int)(id / (unsigned)blocks_per_img);
@@ -95,7 +102,8 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
 #pragma unroll
         for (int i = 0; i < PH; ++i) {
             const int ph = wave + NW * i;
-            if (ph < HPIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(hb + ph * 1024), 16, h_voff[i], (unsigned)cc * 128u, 0, 0);
+            // RING: all PH pieces are issued by every wave (the ones beyond the image are zero fills into the buffer's padding)
+            if (RING || ph < HPIECES) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (gl_lptr)(hb + ph * 1024), 16, h_voff[i], (unsigned)cc * 128u, 0, 0);
         }
     };
     auto stage_w = [&](int kt, char *wb) {
@@ -142,24 +150,66 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
     };
 
     // ---- main loop: chunks of 32 input channels, 9 taps each; one barrier per tap (the weight slice of the tap has landed)
-    stage_halo(0, smem);
-    stage_w(0, wbuf);
-    for (int cc = 0; cc < nchunks; ++cc) {
-        const char *hb = smem + (NHBUF == 2 ? (cc & 1) * HBYTES : 0);
+    if constexpr (!RING) {
+        stage_halo(0, smem);
+        stage_w(0, wbuf);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const char *hb = smem + (NHBUF == 2 ? (cc & 1) * HB : 0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kt = cc * 9 + tap;
-            __syncthreads();                                  // slice kt (and, at tap 0, the halo of this chunk) landed; the other weight buffer is free
-            if (tap < 8) stage_w(kt + 1, wbuf + ((kt + 1) & 1) * W_BYTES);
-            if (NHBUF == 2 && tap == 0 && cc + 1 < nchunks) stage_halo(cc + 1, smem + ((cc + 1) & 1) * HBYTES);
-            compute(hb, wbuf + (kt & 1) * W_BYTES, (tap / 3 - 1) * HALO + (tap % 3 - 1));
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kt = cc * 9 + tap;
+                __syncthreads();                                  // slice kt (and, at tap 0, the halo of this chunk) landed; the other weight buffer is free
+                if (tap < 8) stage_w(kt + 1, wbuf + ((kt + 1) & 1) * W_BYTES);
+                if (NHBUF == 2 && tap == 0 && cc + 1 < nchunks) stage_halo(cc + 1, smem + ((cc + 1) & 1) * HB);
+                compute(hb, wbuf + (kt & 1) * W_BYTES, (tap / 3 - 1) * HALO + (tap % 3 - 1));
+            }
+            if (cc + 1 < nchunks) {
+                if (NHBUF == 1) {
+                    __syncthreads();                              // everyone is done with the halo image
+                    stage_halo(cc + 1, smem);
+                }
+                stage_w((cc + 1) * 9, wbuf + (((cc + 1) * 9) & 1) * W_BYTES);
+            }
         }
-        if (cc + 1 < nchunks) {
-            if (NHBUF == 1) {
-                __syncthreads();                              // everyone is done with the halo image
+    } else {
+        // Per wave the LDS-DMA instructions retire in issue order, and s_waitcnt vmcnt(N) returns when all but the N youngest have: before the
+        // barrier of slice kt a wave waits for its pieces of slice kt (issued two iterations ago) and lets exactly the younger ones fly --
+        // slice kt + 1 (PW pieces) and, when one was requested after slice kt, the next chunk's halo (PH pieces).
+        //   issue order:  H(0) W(0) W(1) | iteration kt: W(kt + 2) [two halo buffers, tap 0: H(cc + 1)]  [one halo buffer, after tap 8: barrier, H(cc + 1)]
+        // The barrier that follows the wait tells every wave that all waves have the slice (and have finished computing slice kt - 1, whose ring
+        // slot W(kt + 2) may now overwrite).
+        const int nk = 9 * nchunks;
+        stage_halo(0, smem);
+        stage_w(0, wbuf);
+        if (nk > 1) stage_w(1, wbuf + W_BYTES);
+        int slot = 0;                                            // ring slot of slice kt
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const char *hb = smem + (NHBUF == 2 ? (cc & 1) * HB : 0);
+            const bool more = cc + 1 < nchunks;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int kt = cc * 9 + tap;
+                if (kt + 1 >= nk) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (NHBUF == 1 && tap == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the halo of this chunk was the last request (no-op cost at cc = 0: W(1) is all that flies)
+                } else if (NHBUF == 2 && (tap == 1 || tap == 2) && more) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + PH) : "memory");  // H(cc + 1), requested at tap 0 behind W(kt) or W(kt + 1)'s predecessor, may fly
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = slot == 0 ? 2 : slot - 1;                            // slot of slice kt + 2 (= slice kt - 1's)
+                if (kt + 2 < nk) stage_w(kt + 2, wbuf + s2 * W_BYTES);
+                if (NHBUF == 2 && tap == 0 && more) stage_halo(cc + 1, smem + ((cc + 1) & 1) * HB);
+                compute(hb, wbuf + slot * W_BYTES, (tap / 3 - 1) * HALO + (tap % 3 - 1));
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            if (NHBUF == 1 && more) {
+                __builtin_amdgcn_s_barrier();                    // everyone is done with the halo image (LDS reads are consumed before a wave gets here)
                 stage_halo(cc + 1, smem);
             }
-            stage_w((cc + 1) * 9, wbuf + (((cc + 1) * 9) & 1) * W_BYTES);
         }
     }
 
@@ -173,15 +223,15 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
 #endif
 }
 
-template <int WC>
+template <int WC, bool RING = false>
 int launch_halo(gl_ctx *ctx, const GlGatherConv &p)
 {
     const int bx = p.W / BLK, by = p.H / BLK;
     const int64_t imgs = p.positions / ((int64_t)p.H * p.W);
     const int64_t total = imgs * bx * by;
     GL_REQUIRE(total < (1ll << 31), "halo_conv_h3: grid too large");
-    constexpr int lds = WC * HBYTES + 2 * 64 * WC * 128;
-    auto kern = halo_conv_h3_kernel<WC>;
+    constexpr int lds = WC * halo_bytes(4 * WC, RING) + (RING ? 3 : 2) * 64 * WC * 128;
+    auto kern = halo_conv_h3_kernel<WC, RING>;
     GL_ONCE_PER_DEVICE(ctx, \
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
@@ -207,5 +257,6 @@ bool gl_conv_halo_applies(const GlGatherConv &p, int phases)
 
 int gl_launch_conv_halo_h3(gl_ctx *ctx, const GlGatherConv &p)
 {
+    if (gl_tuning_int("GL_HALO_RING", 0)) return p.cols <= 64 ? launch_halo<1, true>(ctx, p) : launch_halo<2, true>(ctx, p);
     return p.cols <= 64 ? launch_halo<1>(ctx, p) : launch_halo<2>(ctx, p);
 }

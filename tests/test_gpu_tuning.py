@@ -76,6 +76,19 @@ for v in (1, 0):
     fb = m.features(imgs, role="bank")
     res[v] = (f32.numpy().copy(), u8.numpy().copy(), fb.rows_numpy().copy(), fb.norms.numpy().copy())
 out["t4_equals_raster"] = [bool(np.array_equal(a, b)) for a, b in zip(res[1], res[0])]
+# the halo kernel's ring of three weight slices with counted waits against its two-buffer form (VGG16 conv1_2 / conv2_x at 64 x 64, and a PGGAN block
+# through x2 upsampling at 128 x 128)
+from ganleaks_amd.gan_models.pggan.model_torch import Generator as PGGAN
+pg = PGGAN(128, 128, 3)
+pg.load_state_dict(gl.synth.pggan_state_dict(3, 128, 128))
+zp = gl.synth.latent(12, 40, 128)
+hr = {}
+for v in (1, 0):
+    os.environ["GL_HALO_RING"] = str(v)
+    fb = m.features(imgs, role="bank")
+    hr[v] = (fb.rows_numpy().copy(), fb.norms.numpy().copy(), pg.generate_u8(zp, steps=5, alpha=1.0).numpy().copy())
+os.environ.pop("GL_HALO_RING")
+out["halo_ring_equals_two_buffers"] = [bool(np.array_equal(a, b)) for a, b in zip(hr[1], hr[0])]
 print("RESULT " + json.dumps(out))
 '''
 
@@ -93,3 +106,4 @@ def test_shipped_kernels_match_their_plain_siblings_bit_for_bit():
     assert out["feat_cluster_equals_plain_persistent"] is True, out
     assert out["feat_unsegmented_rel_diff"] < 1e-4 and out["feat_idx_equal_unsegmented"], out
     assert out["t4_equals_raster"] == [True, True, True, True], out
+    assert out["halo_ring_equals_two_buffers"] == [True, True, True], out

@@ -8,7 +8,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-if any(k in os.environ for k in ("GL_TAP_FUSE", "GL_H3_HALO", "GL_H3_TILE128")):      # tuning switches exist only in the tuning build
+if any(k in os.environ for k in ("GL_TAP_FUSE", "GL_H3_HALO", "GL_H3_TILE128", "GL_HALO_RING", "GL_H3_T4")):      # tuning switches exist only in the tuning build
     os.environ.setdefault("GANLEAKS_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gan-leaks_amd", "libganleaks_hip_tuning.so"))
 import ganleaks_amd as gl  # noqa: E402
 from ganleaks_amd.lpips import LpipsModel  # noqa: E402
@@ -27,4 +27,4 @@ for _ in range(reps):
     fb = m.features(imgs, role="bank", out=fb)
 ctx.sync()
 dt = (time.perf_counter() - t0) / reps
-print(json.dumps({"images": n, "ms": round(dt * 1e3, 3), "images_per_s": round(n / dt, 1), "GL_TAP_FUSE": os.environ.get("GL_TAP_FUSE", "1")}))
+print(json.dumps({"images": n, "ms": round(dt * 1e3, 3), "images_per_s": round(n / dt, 1), "GL_TAP_FUSE": os.environ.get("GL_TAP_FUSE", "1"), "GL_HALO_RING": os.environ.get("GL_HALO_RING", "")}))
