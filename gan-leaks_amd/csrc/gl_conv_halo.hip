@@ -257,6 +257,8 @@ bool gl_conv_halo_applies(const GlGatherConv &p, int phases)
 
 int gl_launch_conv_halo_h3(gl_ctx *ctx, const GlGatherConv &p)
 {
+#ifdef GL_TUNING      // measured (round 3, tools/ab_halo_ring.py, alternating in one process): VGG16 features 1.000x, PGGAN-256 0.991x -- not the limiter; tuning build only
     if (gl_tuning_int("GL_HALO_RING", 0)) return p.cols <= 64 ? launch_halo<1, true>(ctx, p) : launch_halo<2, true>(ctx, p);
+#endif
     return p.cols <= 64 ? launch_halo<1>(ctx, p) : launch_halo<2>(ctx, p);
 }
