@@ -222,3 +222,40 @@ def test_fbb_sweep_on_a_device_group(tmp_path, monkeypatch, synth):
     porder = sorted(range(3), key=lambda k: str(tmp_path / "pos" / ("image_%d.png" % k)))
     want = [order.index([0, 64, 127][k]) for k in porder]
     assert [int(v) for v in lr1[3][:, 0]] == want
+
+
+def _gloo_rank(rank, world, port, out_dir):
+    """one process per rank sharing the GPU: its shard of a MATERIALISED bank (rows [bounds[r], bounds[r+1]) of the host array, index_base =
+    bounds[r]) searched for all queries, keys min-reduced through torch.distributed (gloo: ranks on one device cannot form an RCCL communicator)"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch.distributed as dist
+    import ganleaks_amd as gl
+    from ganleaks_amd import shard
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    case = gl.synth.attack_case(512, 1000, 30, 30, 32)
+    q = np.concatenate([case["pos"], case["neg"]])
+    bounds = shard.shard_bounds(len(case["bank"]), 64, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    d, i = gl.attack(q, case["bank"][lo:hi], batch_size=64, index_base=lo, reduce_fn=lambda k: shard.allreduce_min_keys(k))
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "gloo_%d.npz" % world), d=d, i=i)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_materialised_bank_one_process_per_rank_over_gloo(world, tmp_path, synth):
+    import socket
+    import torch.multiprocessing as mp
+    import c_oracle
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / ("gloo_%d.npz" % world))
+    case = synth.attack_case(512, 1000, 30, 30, 32)
+    od, oi, _ = c_oracle.knn_l2_u8(case["bank"], np.concatenate([case["pos"], case["neg"]]), 64)
+    assert np.array_equal(got["i"], oi) and np.array_equal(got["d"], od) and oi.max() < 960
