@@ -60,14 +60,7 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [halo x NHBUF][W x 2 (RING: x 3)]
     char *const wbuf = smem + NHBUF * HB;
 
-    // Persistent form (round 3): a workgroup takes pixel blocks b = blockIdx.x, blockIdx.x + gridDim.x, ... (gridDim.x a multiple of 8, so b and
-    // blockIdx.x share an XCD under the round-robin placement).  The stores of a block are asynchronous: the wave goes on to the next block's
-    // halo requests and MFMAs while they drain, instead of ending -- and holding its slot until they have -- with every workgroup of the chip in
-    // the same phase (timing experiments, tools/diag_halo.py: the stores were 20 - 30 % of the one-block-per-workgroup kernel's time and none of
-    // it overlapped).  gridDim.x = total_blocks gives the old behaviour.
-  for (unsigned bb = blockIdx.x; bb < total_blocks; bb += gridDim.x) {
-    if (bb != blockIdx.x) __syncthreads();                   // the previous block's epilogue is done with the LDS
-    const unsigned id = gl_xcd_remap(bb, total_blocks);
+    const unsigned id = gl_xcd_remap(blockIdx.x, total_blocks);
     const int img = (int)(id / (unsigned)blocks_per_img);
     const int brem = (int)(id % (unsigned)blocks_per_img);
     const int y0 = (brem / blocks_x) * BLK, x0 = (brem % blocks_x) * BLK;
@@ -237,11 +230,10 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
 #pragma unroll
             for (int j = 0; j < TP; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (keep == 123.456f) atomicAdd(p.sat_flag, 1);      // keeps the accumulators alive
-        continue;
+        return;
     }
     const bool saturated = gl_h3::epilogue<WC, WP, TC, TP>(p, acc, 0, wc, wp_, lane, o4, smem, 1);
     if (__any(saturated) && lane == 0) atomicAdd(p.sat_flag, 1);
-  }
 #endif
 }
 
@@ -257,13 +249,7 @@ int launch_halo(gl_ctx *ctx, const GlGatherConv &p)
     GL_ONCE_PER_DEVICE(ctx, \
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
-    // persistent: as many workgroups as the chip holds at once (2 per CU for the 4-wave form, 1 for the 8-wave form), a multiple of 8
-    int64_t grid = total;
-    if (gl_tuning_int("GL_HALO_PERSIST", 1)) {
-        const int64_t resident = (int64_t)(ctx->num_cu > 0 ? ctx->num_cu : 256) * (WC == 1 ? 2 : 1) / 8 * 8;
-        if (resident >= 8 && total > resident) grid = resident;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256 * WC), lds, ctx->stream, p, bx, bx * by, (unsigned)total, gl_tuning_int("GL_HALO_DIAG", 0));
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256 * WC), lds, ctx->stream, p, bx, bx * by, (unsigned)total, gl_tuning_int("GL_HALO_DIAG", 0));
     GL_LAUNCH_CHECK();
     return GL_OK;
 }
@@ -285,7 +271,7 @@ bool gl_conv_halo_applies(const GlGatherConv &p, int phases)
 
 int gl_launch_conv_halo_h3(gl_ctx *ctx, const GlGatherConv &p)
 {
-#ifdef GL_TUNING      // measured (round 3, tools/ab_switch.py GL_HALO_RING, alternating in one process): VGG16 features 1.000x, PGGAN-256 0.991x -- not the limiter; tuning build only
+#ifdef GL_TUNING      // measured (round 3, tools/ab_halo_ring.py, alternating in one process): VGG16 features 1.000x, PGGAN-256 0.991x -- not the limiter; tuning build only
     if (gl_tuning_int("GL_HALO_RING", 0)) return p.cols <= 64 ? launch_halo<1, true>(ctx, p) : launch_halo<2, true>(ctx, p);
 #endif
     return p.cols <= 64 ? launch_halo<1>(ctx, p) : launch_halo<2>(ctx, p);

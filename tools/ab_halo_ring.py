@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of one 0 / 1 tuning switch of libganleaks_hip_tuning.so (argv[1], default GL_HALO_RING) in one process, alternating: VGG16 features at
-64 x 64 and PGGAN-256.      python tools/ab_switch.py GL_HALO_PERSIST"""
+"""A/B of the halo kernel's weight ring (GL_HALO_RING, tuning build) in one process, alternating: VGG16 features at 64 x 64 and PGGAN-256."""
 import json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +9,6 @@ import ganleaks_amd as gl
 from ganleaks_amd.lpips import LpipsModel
 from ganleaks_amd.gan_models.pggan.model_torch import Generator as PGGAN
 ctx = gl.Context.get()
-SWITCH = sys.argv[1] if len(sys.argv) > 1 else "GL_HALO_RING"
 lin = np.load(os.path.join(ROOT, "tests", "golden", "lpips_lin_v0.1.npz"))
 m = LpipsModel().load_state_dicts(gl.synth.vgg16_state_dict(7), {"lin%d" % i: lin["lin%d" % i] for i in range(5)})
 imgs = ctx.to_device(np.random.default_rng(0).integers(0, 256, size=(8192, 3, 64, 64), dtype=np.uint8))
@@ -22,7 +20,7 @@ pg.generate_u8(zp, steps=6, alpha=1.0)
 res = {"vgg": {0: [], 1: []}, "pggan256": {0: [], 1: []}}
 for r in range(4):
     for v in (0, 1):
-        os.environ[SWITCH] = str(v)
+        os.environ["GL_HALO_RING"] = str(v)
         ctx.sync(); t0 = time.perf_counter()
         for _ in range(3):
             fb = m.features(imgs, role="bank", out=fb)
@@ -32,5 +30,5 @@ for r in range(4):
             pg.generate_u8(zp, steps=6, alpha=1.0)
         ctx.sync(); res["pggan256"][v].append((time.perf_counter() - t0) / 2 * 1e3)
 for k, d in res.items():
-    print(json.dumps({"switch": SWITCH, "workload": k, "off_ms": [round(x, 2) for x in d[0]], "on_ms": [round(x, 2) for x in d[1]],
+    print(json.dumps({"workload": k, "two_buffers_ms": [round(x, 2) for x in d[0]], "ring_ms": [round(x, 2) for x in d[1]],
                       "median_ratio": round(float(np.median(d[0]) / np.median(d[1])), 4)}))
