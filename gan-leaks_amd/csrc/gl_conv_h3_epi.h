@@ -248,75 +248,6 @@ __device__ __forceinline__ bool epilogue(const GlGatherConv &p, v4f (&acc)[TC][T
             return saturated;
         }
     }
-    if (p.out_mode == 2) {
-        // ---- split-layout store, turned through LDS (round 3).  A lane holds 4 consecutive channels of one position per tile, i.e. 8-byte pieces
-        // (hi) and 8-byte pieces (lo); stored directly, one instruction writes 16 segments of 32 bytes, and timing experiments on the halo kernel
-        // (tools/diag_halo.py) showed the STORES to be 20 - 30 % of these kernels' time (everything else in the epilogue: 1 - 2 %).  Here the wave
-        // writes the 16 positions of one position tile into its own LDS region in the final byte order -- [position][this wave's channels: per
-        // 32-channel chunk 64 B of hi halves | 64 B of lo halves] -- and reads it back 16 bytes per lane, so that a store instruction writes whole
-        // runs of TC * 64 contiguous bytes per position.  Same values, same bytes in memory.
-        constexpr int ROWB = TC * 64;                           // bytes of one position inside this wave's channel range
-        constexpr int PITCH = ROWB + 16;                        // LDS row pitch (16-byte aligned rows, 2-way conflicts at most on the 8-byte writes)
-        constexpr int LPP = ROWB / 16;                          // lanes per position on the way out
-        constexpr int PPI = 64 / LPP;                           // positions per store instruction
-        constexpr int REGION = 16 * PITCH + 2 * 16 * TC * 4;     // staging rows + this wave's scale / shift table
-        char *stg = smem + 16384 + (wc * WP + wp_) * REGION;
-        float *tbl = reinterpret_cast<float *>(stg + 16 * PITCH);
-        const int chw = c0 + wc * 16 * TC;                      // first channel of this wave
-        const int valid = p.cols - chw < 16 * TC ? (p.cols - chw) * 4 : ROWB;     // bytes of a position's run that exist (cols % 32 == 0)
-        // scale / shift of the wave's channels go through LDS too: held in registers for all TC tiles they cost 8 TC registers, which the 8 x 4
-        // tiles do not have (288 bytes of scratch when tried)
-#pragma unroll
-        for (int idx = lane; idx < 16 * TC; idx += 64) {
-            const int ch = chw + idx;
-            const bool real = !pixnorm && ch < p.cols;
-            const int chm = ch < p.cmod ? ch : ch % p.cmod;
-            tbl[idx] = real ? p.scale[chm] : 0.0f;
-            tbl[16 * TC + idx] = real ? p.shift[chm] : 0.0f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (valid > 0) {
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                const float *tb = tbl + 4 * fk;
-                asm volatile("" : "+v"(tb));                    // re-read per position tile: hoisted out of the loop the table is 8 TC registers again
-#pragma unroll
-                for (int i = 0; i < TC; ++i) {
-                    v4h hi, lo;
-                    const v4f sc = *reinterpret_cast<const v4f *>(tb + i * 16), sh = *reinterpret_cast<const v4f *>(tb + 16 * TC + i * 16);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v;
-                        if (pixnorm) {
-                            v = __fmul_rn(acc[i][j][r], pinv[j]);
-                        } else {
-                            const float t = fmaf(acc[i][j][r], sc[r], sh[r]);
-                            v = fmaxf(fmaxf(t, t * neg_slope), relu_floor);
-                        }
-                        const float c = fminf(fmaxf(v, -65504.0f), 65504.0f);
-                        saturated |= (c != v) && (o4[j] >= 0) && (chw + i * 16 < p.cols);
-                        hi[r] = (_Float16)c;
-                        // after the fused PixelNorm the low half is the exact residual of the product (one fma), as pixelnorm_split_kernel computes it
-                        lo[r] = pixnorm ? (_Float16)fmaf(acc[i][j][r], pinv[j], -(float)hi[r]) : (_Float16)__fsub_rn(c, (float)hi[r]);
-                    }
-                    char *d = stg + frow * PITCH + (i >> 1) * 128 + (i & 1) * 32 + fk * 8;
-                    *reinterpret_cast<v4h *>(d) = hi;
-                    *reinterpret_cast<v4h *>(d + 64) = lo;
-                }
-                __builtin_amdgcn_wave_barrier();                // the region belongs to this wave alone: program order + the LDS counter are enough
-#pragma unroll
-                for (int s = 0; s < 16 / PPI; ++s) {
-                    const int rr = s * PPI + lane / LPP, piece = lane % LPP;
-                    const int o = __shfl(o4[j], rr, 64);        // the lane with frow = rr, fk = 0 holds that row's output position
-                    const uint4 q = *reinterpret_cast<const uint4 *>(stg + rr * PITCH + piece * 16);
-                    if (o >= 0 && piece * 16 < valid)
-                        *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(p.out) + (int64_t)o * p.cols * 4 + (int64_t)chw * 4 + piece * 16) = q;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return saturated;
-    }
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
         const int ch = c0 + wc * 16 * TC + i * 16 + 4 * fk;     // first of this lane's 4 consecutive channels

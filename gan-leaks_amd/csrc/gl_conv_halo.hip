@@ -48,7 +48,7 @@ constexpr int halo_bytes(int nw, bool ring) { return ring ? ((HPIECES + nw - 1) 
 template <int WC, bool RING = false>
 __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGatherConv p, int blocks_x, int blocks_per_img, unsigned total_blocks, int diag)
 {
-    // diag (tuning build only, timing experiments, RESULTS ARE WRONG when set): 1 = no weight DMA inside the loop, 2 = no barrier inside the loop, 4 = no epilogue, 8 = epilogue without its stores
+    // diag (tuning build only, timing experiments, RESULTS ARE WRONG when set): 1 = no weight DMA inside the loop, 2 = no barrier inside the loop, 4 = no epilogue
 #if __HIP_DEVICE_COMPILE__
     constexpr int TC = 4, TP = 4, WP = 4, NW = WC * WP;
     constexpr int HTC = 64 * WC;
@@ -219,10 +219,6 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
     int o4[TP];
 #pragma unroll
     for (int j = 0; j < TP; ++j) o4[j] = (img * p.Ho + y0 + wp_ * 4 + j) * p.Wo + x0 + frow;
-    if (diag & 8) {
-#pragma unroll
-        for (int j = 0; j < TP; ++j) o4[j] = -1;
-    }
     if (diag & 4) {
         float keep = 0.0f;
 #pragma unroll

@@ -14,7 +14,7 @@ fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
 shapes = [("VGG conv1_2 64->64 @64x64 x512", 64, 64, 64, 512), ("VGG conv2_2 128->128 @32x32 x1024", 128, 128, 32, 1024),
           ("PGGAN 128->128 @128x128 x64", 128, 128, 128, 64), ("PGGAN 64->64 @256x256 x32", 64, 64, 256, 32)]
-names = {0: "full", 8: "epilogue without its stores", 4: "no epilogue", 7: "MFMAs + fragment reads only"}
+names = {0: "full", 1: "no weight DMA in the loop", 3: "no DMA, no barrier", 4: "no epilogue", 7: "MFMAs + fragment reads only"}
 for name, cin, cout, hw, n in shapes:
     row = {"layer": name}
     for r in range(2):
