@@ -423,3 +423,30 @@ def test_split_path_on_weights_with_imagenet_like_dynamic_range(gl, synth, lin, 
     od, oi, _ = lpips_oracle.knn_l2_lpips(sd, lins, f(bank), f(q), 16)
     d, i = gl.attack(q, bank, distance="l2-lpips", batch_size=16, lpips=a)
     assert np.array_equal(i, oi) and np.abs(d - od).max() < 5e-6
+
+
+def test_k_blocked_rows_in_both_layouts_and_on_the_float_path(gl, synth, model, lin, oracle):
+    """Search rows of 2 MiB or more are stored K-blocked (include/ganleaks.h gl_lpips_search_rows_capacity).  At 128 x 128 both the lattice rows
+    (4.1 MB) and the hi / lo rows (4.3 MB) are: same neighbours in both, equal to the fp64 oracle's, also when the queries are off-lattice
+    floats (hi / lo on both sides, the fp32 feature entry points) and when the bank is streamed in chunks smaller than one block of 256 rows."""
+    import lpips_oracle
+    from ganleaks_amd.lpips import feat_knn_keys
+    from ganleaks_amd.attack import unpack_keys
+    ctx = gl.Context.get()
+    case = synth.attack_case(131, 20, 2, 2, 128, sigma=20.0)
+    bank, q = case["bank"], np.concatenate([case["pos"], case["neg"]])
+    sd = synth.vgg16_state_dict(7)
+    lins = [lin["lin%d" % i] for i in range(5)]
+    od, oi, _ = lpips_oracle.knn_l2_lpips(sd, lins, oracle.dequantize_u8(bank), oracle.dequantize_u8(q), 4)
+    res = {}
+    for fmt in ("lattice", "hilo"):
+        fb, fq = model.features(bank, role="bank", fmt=fmt), model.features(q, role="query", fmt=fmt)
+        assert fb.blocked and fq.blocked and fb.V.shape[0] == 256 and fb.rows_numpy().shape == (20, fb.K)
+        res[fmt] = unpack_keys(ctx, feat_knn_keys(fb, fq), fq.n, fq.K, "f32")
+        assert np.array_equal(res[fmt][1], oi) and np.abs(res[fmt][0] - od).max() < 5e-6, fmt
+    qf = np.clip(oracle.dequantize_u8(q) + np.random.default_rng(2).normal(0, 0.01, q.shape).astype(np.float32), -1, 1)
+    odf, oif, _ = lpips_oracle.knn_l2_lpips(sd, lins, oracle.dequantize_u8(bank), qf, 4)
+    row = 2 * int(ctx.lib.gl_lpips_search_dim(128, 128))
+    for kw in ({}, {"chunk_bytes": 6 * row}):
+        d, i = gl.attack(qf, bank, distance="l2-lpips", batch_size=4, lpips=model, **kw)
+        assert np.array_equal(i, oif) and np.abs(d - odf).max() < 5e-6, kw
