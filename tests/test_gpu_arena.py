@@ -55,3 +55,33 @@ def test_query_budget_follows_the_device():
     b = _query_budget_bytes(64 << 30, ctx)
     assert b == max(avail - (64 << 30) - (12 << 30), min(64 << 30, avail // 4)) and b < avail
     assert _query_budget_bytes(1 << 30, ctx) == 1 << 30                   # an explicit chunk budget is also the query budget
+
+
+def test_library_allocations_reclaim_the_arena_when_memory_runs_out(synth):
+    """a kept block must never make one of the library's own allocations fail: gl_device_alloc releases the arena and retries.  Nearly all of the
+    device is put into one kept block, then a generator needs its multi-GB workspace."""
+    import ganleaks_amd as gl
+    from ganleaks_amd.gan_models.dcgan.model_torch import Generator
+    ctx = gl.Context(0)
+    try:
+        avail, _ = ctx.mem_info()
+        hog = avail - (3 << 30)                                           # leave 3 GiB: less than the workspace of a 4096-image pass (~5 GiB)
+        if hog < (64 << 30):
+            pytest.skip("device too full for this test")
+        a = ctx.empty((hog,), np.uint8)
+        del a
+        gc.collect()
+        after, _ = ctx.mem_info()
+        assert after >= avail - (256 << 20)                              # kept, and counted as available
+        g = Generator(100, 3, 64, ctx)
+        g.load_state_dict(synth.dcgan_state_dict(1234))
+        z = synth.latent(3, 4096)
+        u8 = g.generate_u8(z)                                            # needs the workspace: the arena block has to go
+        ref = Generator(100, 3, 64)
+        ref.load_state_dict(synth.dcgan_state_dict(1234))
+        assert np.array_equal(u8.numpy(), ref.generate_u8(z).numpy())
+        del u8, g
+        gc.collect()
+    finally:
+        gc.collect()
+        ctx.destroy()
