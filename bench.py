@@ -540,7 +540,7 @@ def live_traffic(args, distance, gen_precision):
     import shutil
     import subprocess
     import tempfile
-    if not shutil.which("rocprofv3"):
+    if not shutil.which("rocprofv3") or live_traffic.failed:
         return None
     tmp = tempfile.mkdtemp(prefix="gl_traffic_", dir="/tmp")
     try:
@@ -551,8 +551,9 @@ def live_traffic(args, distance, gen_precision):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter.lower())
             r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=600)
+                               stderr=subprocess.DEVNULL, timeout=180)
             if r.returncode != 0:
+                live_traffic.failed = True               # one failure (or a pass that hangs: timeout) ends the live measurement for this run
                 return None
             dirs.append(d)
         out = os.path.join(tmp, "summary.json")
@@ -564,9 +565,13 @@ def live_traffic(args, distance, gen_precision):
         return {k: v["hbm_bytes_per_launch"] for k, v in tr.items() if isinstance(v, dict) and "hbm_bytes_per_launch" in v}
     except Exception as e:  # noqa: BLE001  (a measurement aid: never fails the bench)
         log("[traffic] live PMC passes failed: %s" % (e,))
+        live_traffic.failed = True
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+live_traffic.failed = False
 
 
 def apply_live_traffic(line, tr):
