@@ -45,7 +45,7 @@ constexpr int halo_bytes(int nw, bool ring) { return ring ? ((HPIECES + nw - 1) 
 // RING: the weight slices go through a ring of THREE buffers with counted waits (s_waitcnt vmcnt(N) + a raw s_barrier) instead of two buffers
 // behind __syncthreads(): the slice of tap t + 2 is requested while tap t is computed, so a tap's 48 MFMAs per wave (768 cycles at the full rate,
 // about one L2 round trip) no longer have to cover the whole latency of the next slice.  Same K order, same MFMA order: same bits.
-template <int WC, bool RING = false, bool PREFX = false>
+template <int WC, bool RING = false>
 __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGatherConv p, int blocks_x, int blocks_per_img, unsigned total_blocks, int diag)
 {
     // diag (tuning build only, timing experiments, RESULTS ARE WRONG when set): 1 = no weight DMA inside the loop, 2 = no barrier inside the loop, 4 = no epilogue
@@ -150,42 +150,6 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
             }
     };
 
-    // PREFX: the position fragments of tap t + 1 come from the halo image, which is resident for the whole chunk -- unlike the weight slice they
-    // need not wait for the next barrier.  They are read at the top of tap t, behind its weight fragments and ahead of its 48 MFMAs, so the matrix
-    // instructions wait for 8 LDS reads instead of 16 and the other 8 return underneath them.  Same operands, same order of MFMAs: same bits.
-    v8h xh_cur[TP], xl_cur[TP];
-    auto read_x = [&](const char *hb, int delta, v8h (&h)[TP], v8h (&l)[TP]) {
-#pragma unroll
-        for (int j = 0; j < TP; ++j) {
-            const int q = qbase[j] + delta;
-            const char *r = hb + q * 128;
-            h[j] = *reinterpret_cast<const v8h *>(r + ((fk ^ (q & 7)) << 4));
-            l[j] = *reinterpret_cast<const v8h *>(r + (((4 + fk) ^ (q & 7)) << 4));
-        }
-    };
-    auto compute_px = [&](const char *hb, const char *wb, int delta_next, bool more) {
-        v8h w_hi[TC], w_lo[TC], xh_n[TP], xl_n[TP];
-#pragma unroll
-        for (int i = 0; i < TC; ++i) {
-            const char *r = wb + w_row0 + i * 16 * 128;
-            w_hi[i] = *reinterpret_cast<const v8h *>(r + ((fk ^ (frow & 7)) << 4));
-            w_lo[i] = *reinterpret_cast<const v8h *>(r + (((4 + fk) ^ (frow & 7)) << 4));
-        }
-        if (more) read_x(hb, delta_next, xh_n, xl_n);
-#pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int j = 0; j < TP; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_lo[i], xh_cur[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], xl_cur[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w_hi[i], xh_cur[j], acc[i][j], 0, 0, 0);
-            }
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < TP; ++j) { xh_cur[j] = xh_n[j]; xl_cur[j] = xl_n[j]; }
-        }
-    };
-
     // ---- main loop: chunks of 32 input channels, 9 taps each; one barrier per tap (the weight slice of the tap has landed)
     if constexpr (!RING) {
         stage_halo(0, smem);
@@ -198,12 +162,7 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
                 if (!(diag & 2)) __syncthreads();                 // slice kt (and, at tap 0, the halo of this chunk) landed; the other weight buffer is free
                 if (tap < 8 && !(diag & 1)) stage_w(kt + 1, wbuf + ((kt + 1) & 1) * W_BYTES);
                 if (NHBUF == 2 && tap == 0 && cc + 1 < nchunks) stage_halo(cc + 1, smem + ((cc + 1) & 1) * HB);
-                if constexpr (PREFX) {
-                    if (tap == 0) read_x(hb, -HALO - 1, xh_cur, xl_cur);          // the first tap of a chunk: its halo has only just landed
-                    compute_px(hb, wbuf + (kt & 1) * W_BYTES, ((tap + 1) / 3 - 1) * HALO + ((tap + 1) % 3 - 1), tap < 8);
-                } else {
-                    compute(hb, wbuf + (kt & 1) * W_BYTES, (tap / 3 - 1) * HALO + (tap % 3 - 1));
-                }
+                compute(hb, wbuf + (kt & 1) * W_BYTES, (tap / 3 - 1) * HALO + (tap % 3 - 1));
             }
             if (cc + 1 < nchunks) {
                 if (NHBUF == 1) {
@@ -274,7 +233,7 @@ __global__ void __launch_bounds__(256 * WC, 2) halo_conv_h3_kernel(const GlGathe
 #endif
 }
 
-template <int WC, bool RING = false, bool PREFX = false>
+template <int WC, bool RING = false>
 int launch_halo(gl_ctx *ctx, const GlGatherConv &p)
 {
     const int bx = p.W / BLK, by = p.H / BLK;
@@ -282,7 +241,7 @@ int launch_halo(gl_ctx *ctx, const GlGatherConv &p)
     const int64_t total = imgs * bx * by;
     GL_REQUIRE(total < (1ll << 31), "halo_conv_h3: grid too large");
     constexpr int lds = WC * halo_bytes(4 * WC, RING) + (RING ? 3 : 2) * 64 * WC * 128;
-    auto kern = halo_conv_h3_kernel<WC, RING, PREFX>;
+    auto kern = halo_conv_h3_kernel<WC, RING>;
     GL_ONCE_PER_DEVICE(ctx, \
         GL_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)););
     gl_prof_scope prof_(ctx, GL_PROF_GATHER_CONV);
@@ -311,6 +270,5 @@ int gl_launch_conv_halo_h3(gl_ctx *ctx, const GlGatherConv &p)
 #ifdef GL_TUNING      // measured (round 3, tools/ab_halo_ring.py, alternating in one process): VGG16 features 1.000x, PGGAN-256 0.991x -- not the limiter; tuning build only
     if (gl_tuning_int("GL_HALO_RING", 0)) return p.cols <= 64 ? launch_halo<1, true>(ctx, p) : launch_halo<2, true>(ctx, p);
 #endif
-    if (gl_tuning_int("GL_HALO_PREFX", 1)) return p.cols <= 64 ? launch_halo<1, false, true>(ctx, p) : launch_halo<2, false, true>(ctx, p);
     return p.cols <= 64 ? launch_halo<1>(ctx, p) : launch_halo<2>(ctx, p);
 }
